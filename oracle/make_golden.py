@@ -1,0 +1,266 @@
+"""ORACLE tooling (test infrastructure): generate tests/golden/*.npz from the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference); the GPU box never runs it.  It composes, exactly as
+`MyViT` does (src/models/specvit.py:32-35, 68-94):
+
+    vc  = src.models.builder.get_vit_config(cfg)            (reference)
+    vit = transformers.ViTModel(vc)                         (installed 5.15; the reference pins 4.56, same math)
+    vit.embeddings = src.models.embedding.SpectraEmbeddings(vc)   (reference)
+    cls = vit(x)[0][:, 0, :];  logits = Linear(cls);  loss = MSE|L1|CE
+
+`MyViT` itself cannot be constructed against transformers 5.x (it never calls post_init()), and
+`lightning`/`h5py` are not installed, so those *absent third-party packages* are stubbed in-memory just far enough for
+`import src.models` to succeed.  Nothing of the reference is copied: fixtures hold inputs and expected outputs only.
+
+Every fixture is cross-checked against oracle/refvit.py (the restatement) before it is written, which is what pins
+the oracle.  Usage:  python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import refvit  # noqa: E402
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    if "lightning" not in sys.modules:
+        L = stub("lightning", LightningModule=type("LightningModule", (object,), {}),
+                 LightningDataModule=type("LightningDataModule", (object,), {}),
+                 Trainer=type("Trainer", (object,), {}), seed_everything=lambda *a, **k: None)
+        pt = stub("lightning.pytorch")
+        cb = stub("lightning.pytorch.callbacks", Callback=type("Callback", (object,), {}))
+        pt.callbacks = cb
+        L.pytorch = pt
+    if "h5py" not in sys.modules:
+        stub("h5py")
+    import transformers.models.vit.modeling_vit as mv
+    if not hasattr(mv, "ViTSelfAttention"):  # name removed in transformers 5 (vit_with_rope.py:8 imports it)
+        mv.ViTSelfAttention = mv.ViTAttention
+    from src.models.builder import get_vit_config
+    from src.models.embedding import SpectraEmbeddings
+    from src.utils import make_dummy_spectra
+    return get_vit_config, SpectraEmbeddings, make_dummy_spectra
+
+
+def name_456_to_515(name: str) -> str:
+    """transformers-4.56 state_dict name (what the reference's checkpoints hold) -> the installed 5.15 ViTModel name."""
+    n = name
+    assert n.startswith("vit.")
+    n = n[4:]
+    n = n.replace("encoder.layer.", "layers.")
+    n = n.replace("attention.attention.query", "attention.q_proj")
+    n = n.replace("attention.attention.key", "attention.k_proj")
+    n = n.replace("attention.attention.value", "attention.v_proj")
+    n = n.replace("attention.output.dense", "attention.o_proj")
+    n = n.replace("intermediate.dense", "mlp.fc1")
+    if ".output.dense" in n:
+        n = n.replace("output.dense", "mlp.fc2")
+    return n
+
+
+def build_reference(cfg_dict, sd, get_vit_config, SpectraEmbeddings):
+    from transformers import ViTModel
+
+    vc = get_vit_config(cfg_dict)
+    vc._attn_implementation = "eager"  # so attentions are returned (same math as sdpa, SURVEY 8c: diff 7e-7)
+    vit = ViTModel(vc)
+    vit.embeddings = SpectraEmbeddings(vc)
+    own = vit.state_dict()
+    mapped = {}
+    head = {}
+    for k, v in sd.items():
+        if k.startswith("vit."):
+            mapped[name_456_to_515(k)] = v.clone()
+        else:
+            head[k] = v.clone()
+    missing = set(own.keys()) - set(mapped.keys())
+    extra = set(mapped.keys()) - set(own.keys())
+    assert not missing and not extra, (missing, extra)
+    vit.load_state_dict(mapped, strict=True)
+    hname = "classifier" if vc.task_type == "cls" else "regressor"
+    lin = torch.nn.Linear(vc.hidden_size, vc.num_labels)
+    lin.weight.data.copy_(head[hname + ".weight"])
+    lin.bias.data.copy_(head[hname + ".bias"])
+    return vc, vit, lin
+
+
+def ref_forward(vc, vit, lin, rcfg, x, labels, training=False):
+    vit.train(training)
+    o = vit(x, output_hidden_states=True, output_attentions=True)
+    cls = o.last_hidden_state[:, 0, :]
+    logits = lin(cls)
+    loss = refvit.loss_fn(rcfg, logits, labels)  # specvit.py:81-89 (three torch loss calls; restated in refvit.loss_fn)
+    return o, logits, loss
+
+
+def cfg_dict_for(rc: refvit.RefConfig, param: str = "log_g"):
+    return {
+        "model": dict(name="vit", task_type=rc.task_type, image_size=rc.image_size, patch_size=rc.patch_size,
+                      hidden_size=rc.hidden_size, num_hidden_layers=rc.num_hidden_layers,
+                      num_attention_heads=rc.num_attention_heads, stride_size=rc.stride_size, proj_fn=rc.proj_fn,
+                      num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type),
+        "loss": {"name": rc.loss_name},
+        "data": {"param": param},
+    }
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def sample_idx(numel, k, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return np.sort(rng.choice(numel, size=min(k, numel), replace=False)).astype(np.int64)
+
+
+def make_one(tag, rc, param, batch, wseed, xseed, full_grads, x_override=None, steps=3):
+    get_vit_config, SpectraEmbeddings, make_dummy_spectra = _import_reference()
+    cfgd = cfg_dict_for(rc, param)
+    # the reference's own config mapping must agree with the restatement
+    vc0 = get_vit_config({k: dict(v) for k, v in cfgd.items()})
+    rc2 = refvit.config_from_dict({k: dict(v) for k, v in cfgd.items()})
+    assert (vc0.num_labels, vc0.hidden_size, vc0.intermediate_size, vc0.layer_norm_eps) == \
+           (rc2.num_labels, rc2.hidden_size, rc2.intermediate_size, rc2.layer_norm_eps)
+    assert rc2 == rc, (rc2, rc)
+    sd = refvit.make_state_dict(rc, wseed)
+    flux, error, labels = refvit.make_inputs(rc, batch, xseed)
+    if x_override is not None:
+        flux = x_override(make_dummy_spectra, flux)
+    vc, vit, lin = build_reference(cfgd, sd, get_vit_config, SpectraEmbeddings)
+    assert vit.embeddings.num_patches == rc.num_patches
+
+    # ---- eval forward, fp32: reference vs restatement
+    with torch.no_grad():
+        o, logits, loss = ref_forward(vc, vit, lin, rc, flux, labels)
+        mine = refvit.forward(rc, sd, flux, labels, output_hidden_states=True, output_attentions=True)
+        tok_ref = vit.embeddings.patch_embeddings(flux)
+    errs = {
+        "tokens": rel(mine.tokens, tok_ref),
+        "last": rel(mine.last_hidden_state, o.last_hidden_state),
+        "logits": rel(mine.logits, logits),
+        "loss": abs(float(mine.loss) - float(loss)) / (abs(float(loss)) + 1e-30),
+    }
+    for i, (a, b) in enumerate(zip(mine.hidden_states, o.hidden_states)):
+        errs[f"hs{i}"] = rel(a, b)
+    for i, (a, b) in enumerate(zip(mine.attentions, o.attentions)):
+        errs[f"att{i}"] = rel(a, b)
+    worst = max(errs.values())
+    print(f"[{tag}] oracle-vs-reference eval fwd: worst rel err {worst:.3e}")
+    assert worst < 2e-5, errs
+
+    # ---- the reference under bf16 autocast (precision='bf16-mixed', basemodule.py:233) for the bf16 criterion
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ob, logits_b, loss_b = ref_forward(vc, vit, lin, rc, flux, labels)
+    print(f"[{tag}] reference bf16-autocast vs fp32: logits rel {rel(logits_b.float(), logits):.3e} "
+          f"last rel {rel(ob.last_hidden_state.float(), o.last_hidden_state):.3e}")
+
+    # ---- gradients with dropout off (train mode arithmetic == eval arithmetic at p=0): reference autograd
+    for p in list(vit.parameters()) + list(lin.parameters()):
+        p.grad = None
+    vit.eval()
+    o2, logits2, loss2 = ref_forward(vc, vit, lin, rc, flux, labels)
+    loss2.backward()
+    ref_grads = {}
+    inv = {name_456_to_515(k): k for k in sd if k.startswith("vit.")}
+    for k, p in vit.named_parameters():
+        ref_grads[inv[k]] = None if p.grad is None else p.grad.detach().clone()
+    ref_grads[rc.head_name + ".weight"] = lin.weight.grad.detach().clone()
+    ref_grads[rc.head_name + ".bias"] = lin.bias.grad.detach().clone()
+
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    o3 = refvit.forward(rc, tr.params, flux, labels)
+    o3.loss.backward()
+    gworst = 0.0
+    for k, p in tr.params.items():
+        g = ref_grads[k]
+        if g is None or float(g.norm()) < 1e-6:
+            # pooler: no grad at all; key.bias: analytically zero (softmax is shift-invariant), rounding noise only
+            assert p.grad is None or float(p.grad.norm()) < 1e-6, k
+            continue
+        gworst = max(gworst, rel(p.grad, g))
+    print(f"[{tag}] oracle-vs-reference grads: worst rel err {gworst:.3e}")
+    assert gworst < 5e-4, gworst
+
+    # ---- 1..steps optimisation steps (clip 0.5, AdamW lr 1e-3 wd 0), dropout off
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    losses, gnorms, after = [], [], {}
+    for s in range(steps):
+        losses.append(tr.step(flux, labels))
+        gnorms.append(tr.last_grad_norm)
+        if s in (0, steps - 1):
+            after[s + 1] = tr.state_dict()
+
+    out = dict(
+        wseed=np.int64(wseed), xseed=np.int64(xseed), batch=np.int64(batch),
+        flux=flux.numpy(), labels=labels.numpy(),
+        tokens=tok_ref.numpy(), last_hidden_state=o.last_hidden_state.numpy(), logits=logits.numpy(),
+        loss=np.float32(loss), attn0=o.attentions[0].numpy(), attn_last=o.attentions[-1].numpy(),
+        hidden_states=np.stack([h.numpy() for h in o.hidden_states]),
+        bf16_logits=logits_b.float().numpy(), bf16_last_hidden_state=ob.last_hidden_state.float().numpy(),
+        bf16_loss=np.float32(loss_b.float()),
+        step_losses=np.asarray(losses, np.float64), step_grad_norms=np.asarray(gnorms, np.float64),
+        weight_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
+    )
+    names = list(sd.keys())
+    out["param_names"] = np.asarray(names)
+    out["grad_norms"] = np.asarray([0.0 if ref_grads[k] is None else float(ref_grads[k].norm()) for k in names])
+    for i, k in enumerate(names):
+        g = ref_grads[k]
+        if g is None:
+            continue
+        if full_grads:
+            out[f"grad/{k}"] = g.numpy()
+            out[f"after1/{k}"] = after[1][k].numpy()
+            out[f"after{steps}/{k}"] = after[steps][k].numpy()
+        else:
+            idx = sample_idx(g.numel(), 64, 1000 + i)
+            out[f"gidx/{k}"] = idx
+            out[f"grad/{k}"] = g.flatten()[idx].numpy()
+            out[f"after1/{k}"] = after[1][k].flatten()[idx].numpy()
+            out[f"after{steps}/{k}"] = after[steps][k].flatten()[idx].numpy()
+    path = os.path.join(ROOT, "tests", "golden", f"{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # C1: configs/exp/att_clp/baseline.yaml; two of the four rows come from the reference's make_dummy_spectra
+    def c1_inputs(make_dummy_spectra, flux):
+        d = make_dummy_spectra(n=2, length=4096, seed=0)  # src/utils.py:131-139
+        return torch.cat([flux[:2], d], dim=0)
+
+    make_one("c1", refvit.named_config("C1"), "log_g", 4, 11, 12, True, c1_inputs)
+    make_one("c2", refvit.named_config("C2"), "log_g", 2, 21, 22, False)
+    # ragged: overlapping stride with a zero-padded tail patch (tokenization.py:46-48), 3 regression targets, L1 loss
+    r1 = refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          stride_size=48, num_labels=3, loss_name="l1")
+    make_one("r1", r1, "Teff,log_g,M_H", 3, 31, 32, True)
+    # classification head + learned position embeddings (embedding.py:61-66, 95-97; specvit.py:45-48)
+    k1 = refvit.RefConfig(image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                          stride_size=32, task_type="cls", num_labels=5, pos_encoding_type="learned", loss_name="ce")
+    make_one("k1", k1, "log_g", 6, 41, 42, True)
+
+
+if __name__ == "__main__":
+    main()
