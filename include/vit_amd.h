@@ -1,0 +1,172 @@
+/* vit_amd.h -- C ABI of libvit_amd.so: the MI355X (gfx950) kernels behind the ViT training hot path of ViskaWei/VIT.
+ *
+ * The reference has no FFI layer: its boundary is the Python object surface that Lightning calls
+ * (SURVEY.md section 8b).  This header is therefore the boundary the build's own host side (the vit_amd Python package, which
+ * mirrors that surface) binds through ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ * Each entry point cites the reference code whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); nothing is allocated inside except the handle;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no call synchronises the device;
+ *   - return value: VIT_OK or a negative vit_status; vit_last_error() returns a thread-local message;
+ *   - `dtype` arguments are vit_dtype codes; row-major tensors; "ld*" = leading dimension in ELEMENTS;
+ *   - alignment: every base pointer 16-byte aligned, every leading/inner dimension of a bf16 GEMM operand a multiple
+ *     of 8 elements (of an f32 one: 4), checked on the host before any launch (VIT_ERR_ARG otherwise);
+ *   - dropout masks are a pure function of (seed, site, row, col): forward and backward regenerate them, nothing is
+ *     stored.
+ */
+#ifndef VIT_AMD_H_
+#define VIT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_AMD_VERSION 100
+
+typedef struct vit_ctx* vit_handle;
+typedef void* vit_stream; /* hipStream_t */
+
+typedef enum { VIT_OK = 0, VIT_ERR_ARG = -1, VIT_ERR_HIP = -2, VIT_ERR_UNSUPPORTED = -3, VIT_ERR_WORKSPACE = -4 } vit_status;
+typedef enum { VIT_F32 = 0, VIT_BF16 = 1 } vit_dtype;
+typedef enum { VIT_ACT_NONE = 0, VIT_ACT_GELU = 1, VIT_ACT_DGELU = 2 } vit_act;
+typedef enum { VIT_LOSS_MSE = 0, VIT_LOSS_L1 = 1, VIT_LOSS_CE = 2 } vit_loss;
+
+int vit_version(void);
+const char* vit_last_error(void);
+
+/* Handle: device id + a caller-owned workspace (split-K slabs, reduction partials). */
+int vit_create(vit_handle* out, int device);
+int vit_destroy(vit_handle h);
+int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * C = epilogue(alpha * op(A) * op(B)), bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ * Replaces every nn.Linear on the path: tokenization.py:41,50 (patch projection); HF ViTSelfAttention
+ * query/key/value (restated at vit_with_rope.py:54-56), ViTSelfOutput.dense, ViTIntermediate.dense, ViTOutput.dense
+ * and their autograd backward (dX = dY*W, dW = dY^T*X).
+ *   a_trans = 0: A stored [M][K] (lda >= K)      a_trans = 1: A stored [K][M] (lda >= M)
+ *   b_trans = 0: B stored [N][K] (ldb >= K; the nn.Linear weight layout)   b_trans = 1: B stored [K][N]
+ * Epilogue, in this order, on the fp32 accumulator v of element (m, n):
+ *   v = alpha*v + bias[n];  ACT_GELU: (aux_out[m,n] = bf16(v) if aux_out), v = gelu_erf(v);
+ *   ACT_DGELU: v *= gelu_erf'(aux_in[m,n]);  dropout(p, seed, site) as a function of (out_row, n);
+ *   v += residual[out_row, n];  C[out_row, n] = (c_dtype) v
+ * with out_row = (m / rows_per_batch) * out_batch_rows + (m % rows_per_batch) + out_row_offset when
+ * rows_per_batch > 0 (patch-embed writes token rows 1..N of each sample, embedding.py:87-88), else out_row = m.
+ * split_k > 1 accumulates partial products in the handle's workspace and reduces them deterministically (no float
+ * atomics: the reference runs with deterministic=True, basemodule.py:250); only alpha and C (f32) apply then.
+ */
+typedef struct vit_gemm_desc {
+  int M, N, K;
+  int a_trans, b_trans;
+  int ab_dtype;            /* VIT_BF16 (VIT_F32 operands: split-bf16 "x3" mode) */
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc; int c_dtype;
+  float alpha;
+  const float* bias;       /* [N] or NULL */
+  int act;                 /* vit_act */
+  void* aux_out;           /* ACT_GELU: optional bf16 [M,N] pre-activation (ld = ldaux) */
+  const void* aux_in;      /* ACT_DGELU: bf16 [M,N] pre-activation (ld = ldaux) */
+  int64_t ldaux;
+  float dropout_p; uint64_t seed; uint64_t site;
+  const float* residual; int64_t ldres;   /* f32, indexed by out_row */
+  int rows_per_batch, out_batch_rows, out_row_offset;
+  int split_k;             /* 0/1 = off; >1 = that many K slices; -1 = choose */
+  int accumulate;          /* split_k path: C += result instead of C = result */
+} vit_gemm_desc;
+int vit_gemm(vit_handle h, const vit_gemm_desc* d, vit_stream stream);
+
+/* Convenience forms named after SURVEY.md section 8b.  x:[M,K] bf16, W:[N,K] bf16 (nn.Linear layout), y:[M,N]. */
+int vit_linear_fwd(vit_handle h, const void* x, const void* W, const float* bias, void* y, int y_dtype, int M, int N,
+                   int K, int act, void* aux_out, float dropout_p, uint64_t seed, uint64_t site,
+                   const float* residual, vit_stream stream);
+/* dX[M,K] = dY[M,N] * W[N,K]  (optionally *= gelu'(aux_in)) */
+int vit_linear_bwd_dx(vit_handle h, const void* dy, const void* W, void* dx, int dx_dtype, int M, int N, int K,
+                      const void* dgelu_aux_in, vit_stream stream);
+/* dW[N,K] (f32) (+)= dY[M,N]^T * X[M,K], deterministic split-K over M */
+int vit_linear_bwd_dw(vit_handle h, const void* dy, const void* x, float* dW, int M, int N, int K, int accumulate,
+                      vit_stream stream);
+
+/* ------------------------------------------------------------------------------------------- LayerNorm
+ * HF nn.LayerNorm(hidden, eps=layer_norm_eps=1e-12) (builder.py:250): layernorm_before/after and vit.layernorm.
+ * x: f32 [rows, D] (the residual stream is kept in fp32); y: y_dtype [rows, D]; mean/rstd: f32 [rows] (saved for bwd).
+ */
+int vit_layernorm_fwd(vit_handle h, const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int rows, int D, float eps, vit_stream stream);
+/* dx[rows,D] (f32) = LN'(dy) (+ dres if not NULL: the residual branch's gradient); dgamma/dbeta (f32 [D]) are
+ * reduced deterministically through the workspace; accumulate!=0 adds into them. dy: dy_dtype [rows, D]. */
+int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                      const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                      float* dbeta, int rows, int D, vit_stream stream);
+
+/* ------------------------------------------------------------------------------------------- Attention
+ * softmax(Q K^T * scale) -> dropout -> * V, per (batch, head); flash-style (scores never reach HBM).
+ * Replaces HF ViTSelfAttention's eager arithmetic as restated in vit_with_rope.py:63-81 (no logit clamp exists in
+ * the reference: SURVEY.md section 0.4).  qkv: bf16 [B*T, 3*H*dh] token-major, columns [q | k | v], head h at
+ * columns h*dh (the fused QKV projection's natural output; equals view(B,T,H,dh).transpose(1,2) of each third).
+ * ctx: bf16 [B*T, H*dh] (= context_layer after transpose+view, vit_with_rope.py:75-78); lse: f32 [B*H, T]
+ * (log-sum-exp of the scaled scores, saved for backward).
+ */
+int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int B, int H, int T, int dh, float scale,
+                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
+/* dqkv: bf16 [B*T, 3*H*dh] from dctx: bf16 [B*T, H*dh]; recomputes probabilities from lse. delta: f32 [B*H, T]
+ * scratch (rowsum(dctx*ctx)), written by this call. */
+int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                      float* delta, void* dqkv, int B, int H, int T, int dh, float scale, float dropout_p,
+                      uint64_t seed, uint64_t site, vit_stream stream);
+/* Attention probabilities [B, H, T, T] f32 (eval-mode, for output_attentions=True: specvit.py:92-93). */
+int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int B, int H, int T, int dh, float scale,
+                        vit_stream stream);
+
+/* ------------------------------------------------------------------------------- Embedding-side kernels
+ * x.unfold(1,P,S) (+ zero pad of the ragged tail patch) -> bf16 patches [B*N, P]   (tokenization.py:45-49) */
+int vit_unfold_cast(vit_handle h, const float* x, void* patches, int B, int L, int P, int S, int N, vit_stream stream);
+/* rows 0 of every sample <- cls_token (embedding.py:87-88); optional "+ position_embeddings" (embedding.py:95-97)
+ * and the embedding dropout (embedding.py:100) over the whole [B, T, D] f32 token tensor, in place. */
+int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float* pos, int B, int T, int D,
+                     float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
+/* backward of the two above: dtokens [B,T,D] f32 -> dpatch_out bf16 [B*N, D] (dropout mask applied), dcls [D],
+ * dpos [T,D] or NULL. */
+int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, float* dcls, float* dpos, int B, int T,
+                         int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate, vit_stream stream);
+
+/* ------------------------------------------------------------------------------- Elementwise / reductions
+ * dy (bf16 [rows, cols]) = dropout_mask(seed,site) * dx (f32); also the gradient of "dropout(y) + residual" wrt y */
+int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int rows, int cols, float dropout_p, uint64_t seed,
+                         uint64_t site, vit_stream stream);
+/* out[cols] (f32) (+)= column sums of a [rows, cols] tensor (bias gradients), deterministic two-stage */
+int vit_colsum(vit_handle h, const void* a, int a_dtype, int64_t lda, float* out, int rows, int cols, int accumulate,
+               vit_stream stream);
+/* f32 -> bf16 copy (weights after an optimizer step, inputs) */
+int vit_cast_f32_bf16(vit_handle h, const float* src, void* dst, int64_t n, vit_stream stream);
+
+/* ------------------------------------------------------------------------------------- Head + loss
+ * logits[B, C] = cls_rows * W^T + b, cls_rows = last_hidden[:, 0, :] (specvit.py:78-81); loss (specvit.py:83-89):
+ * MSE / L1 over logits.view(-1) vs labels.view(-1) (mean), or cross-entropy over int64 labels (mean).
+ * last_hidden: f32 [B, T, D]; loss_out: f32 [1]. labels may be NULL (loss_out untouched). */
+int vit_head_loss_fwd(vit_handle h, const float* last_hidden, const float* W, const float* b, const void* labels,
+                      float* logits, float* loss_out, int B, int T, int D, int C, int loss_kind, vit_stream stream);
+/* d(last_hidden) (zero except the CLS rows), dW [C,D], db [C] given dloss (f32 [1], the upstream scalar gradient). */
+int vit_head_loss_bwd(vit_handle h, const float* last_hidden, const float* W, const float* logits, const void* labels,
+                      const float* dloss, float* dlast_hidden, float* dW, float* db, int B, int T, int D, int C,
+                      int loss_kind, int accumulate, vit_stream stream);
+
+/* ------------------------------------------------------------------------------------- Optimizer
+ * Global L2 norm (squared) of a flat f32 gradient buffer -> out[0] (Lightning gradient_clip_val=0.5, norm clipping:
+ * basemodule.py:244). Deterministic two-stage reduction. */
+int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream);
+/* torch.optim.AdamW step (opt/optimizer.py:16,108: lr, weight_decay=0 by default) over a flat parameter buffer, with
+ * the clip coefficient min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) applied to g on the fly (sqnorm may be NULL).
+ * Also refreshes the bf16 shadow copy used by the GEMMs (p_bf16 may be NULL). bias_correction uses `step` (1-based). */
+int vit_adamw_step(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* sqnorm,
+                   float max_norm, vit_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_AMD_H_ */

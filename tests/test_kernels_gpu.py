@@ -1,0 +1,351 @@
+"""Kernel numerics on the GPU: every HIP kernel against a plain PyTorch fp32 reference of the same op (computed on
+bf16-rounded operands where the kernel consumes bf16).  All calls go through the C ABI (vit_amd.functional -> ctypes)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def randn(shape, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+GEMM_SHAPES = [(128, 128, 64), (320, 192, 192), (104, 40, 72), (516, 96, 32), (2064, 768, 768), (256, 3072, 768), (640, 768, 3072)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+def test_gemm_layouts(dev, M, N, K, layout):
+    import vit_amd.functional as vf
+
+    # nt: A [M,K], B [N,K] (forward) | nn: B stored [K,N] (dX) | tn: A stored [K,M], B stored [K,N] (dW) | tt: A [K,M], B [N,K]
+    a_t = layout in ("tn", "tt")
+    b_t = layout in ("nn", "tn")
+    A = bf(randn((M, K), dev, 1))
+    Bm = bf(randn((N, K), dev, 2))
+    ref = A.float() @ Bm.float().t()
+    a_store = A.t().contiguous() if a_t else A
+    b_store = Bm.t().contiguous() if b_t else Bm
+    if a_t and M % 8:
+        pytest.skip("transposed A needs M % 8 == 0")
+    out = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.float32)
+    assert rel(out, ref) < 2e-5, (layout, rel(out, ref))
+    out16 = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.bfloat16)
+    assert rel(out16, ref) < 4e-3
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric B catches swapped row/col maps (CDNA guide, section 3)."""
+    import vit_amd.functional as vf
+
+    n = 128
+    A = bf(torch.eye(n, device=dev))
+    Bm = bf(torch.arange(n * n, device=dev, dtype=torch.float32).reshape(n, n) % 251)
+    out = vf.gemm(A, Bm, M=n, N=n, K=n, out_dtype=torch.float32)
+    assert torch.equal(out, Bm.float().t().contiguous())
+    out = vf.gemm(A, Bm, M=n, N=n, K=n, b_trans=True, out_dtype=torch.float32)
+    assert torch.equal(out, Bm.float())
+    out = vf.gemm(Bm, A, M=n, N=n, K=n, a_trans=True, out_dtype=torch.float32)
+    assert torch.equal(out, Bm.float().t().contiguous())
+
+
+def test_gemm_epilogues(dev):
+    import vit_amd.functional as vf
+    from vit_amd._cabi import ACT_DGELU, ACT_GELU
+
+    M, N, K = 330, 256, 192
+    x, W = bf(randn((M, K), dev, 3)), bf(randn((N, K), dev, 4, 0.1))
+    bias = randn((N,), dev, 5)
+    res = randn((M, N), dev, 6)
+    base = x.float() @ W.float().t() + bias
+    # bias + GELU + saved pre-activation
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    y = vf.linear_fwd(x, W, bias, act=ACT_GELU, aux_out=aux)
+    assert rel(aux, base) < 4e-3
+    assert rel(y, F.gelu(base)) < 5e-3
+    # bias + residual, f32 out
+    y = vf.linear_fwd(x, W, bias, out_dtype=torch.float32, residual=res)
+    assert rel(y, base + res) < 2e-5
+    # dX with dgelu
+    dy = bf(randn((M, N), dev, 7))
+    u = bf(randn((M, K), dev, 8))
+    dx = vf.linear_bwd_dx(dy, W, dgelu_aux=u, out_dtype=torch.float32)
+    uu = u.float().requires_grad_(True)
+    F.gelu(uu).backward(dy.float() @ W.float())
+    assert rel(dx, uu.grad) < 2e-5
+    # dW (split-K over M) and accumulate
+    dw = vf.linear_bwd_dw(dy, x)
+    refdw = dy.float().t() @ x.float()
+    assert rel(dw, refdw) < 2e-5
+    dw2 = vf.linear_bwd_dw(dy, x, out=dw.clone(), accumulate=True)
+    assert rel(dw2, 2 * refdw) < 2e-5
+    # row map: rows b*rpb + n -> b*orb + n + 1
+    Bn, rpb = 6, 55
+    xx = bf(randn((Bn * rpb, K), dev, 9))
+    out = torch.full((Bn * (rpb + 1), N), 7.0, dtype=torch.float32, device=dev)
+    vf.gemm(xx, W, M=Bn * rpb, N=N, K=K, out=out, bias=bias, row_map=(rpb, rpb + 1, 1))
+    ref = (xx.float() @ W.float().t() + bias).view(Bn, rpb, N)
+    o3 = out.view(Bn, rpb + 1, N)
+    assert rel(o3[:, 1:], ref) < 2e-5
+    assert torch.all(o3[:, 0] == 7.0)
+
+
+def test_gemm_split_k_explicit(dev):
+    import vit_amd.functional as vf
+
+    M, N, K = 96, 64, 4096
+    a, b = bf(randn((M, K), dev, 10)), bf(randn((N, K), dev, 11))
+    ref = a.float() @ b.float().t()
+    for sk in (2, 5, 64):
+        out = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32, split_k=sk)
+        assert rel(out, ref) < 2e-5
+    # determinism: bitwise equal across runs
+    o1 = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32, split_k=8)
+    o2 = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32, split_k=8)
+    assert torch.equal(o1, o2)
+
+
+def test_gemm_dropout_mask_consistency(dev):
+    import vit_amd.functional as vf
+
+    M, N, K = 512, 384, 64
+    x = bf(torch.zeros((M, K), device=dev))
+    W = bf(torch.zeros((N, K), device=dev))
+    ones = torch.ones((N,), device=dev)
+    drop = (0.1, 1234, 7)
+    y = vf.linear_fwd(x, W, ones, out_dtype=torch.float32, dropout=drop)   # = mask * scale
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    scale = y.max().item()
+    assert abs(scale - 1 / 0.9) < 1e-3
+    dy = vf.dropout_bwd_cast(torch.ones((M, N), device=dev), drop)
+    assert torch.equal(dy.float() != 0, y != 0)
+    # another site / seed gives another mask
+    y2 = vf.linear_fwd(x, W, ones, out_dtype=torch.float32, dropout=(0.1, 1234, 8))
+    assert not torch.equal(y2 != 0, y != 0)
+    # columns and rows are not correlated
+    m = (y != 0).float()
+    assert abs(m.mean(0).std().item()) < 0.03 and abs(m.mean(1).std().item()) < 0.03
+
+
+@pytest.mark.parametrize("rows,D", [(516, 32), (320, 192), (1000, 768), (77, 1024), (33, 2048)])
+def test_layernorm(dev, rows, D):
+    import vit_amd.functional as vf
+
+    x = randn((rows, D), dev, 20) * 3 + 0.5
+    g, b = randn((D,), dev, 21) * 0.1 + 1, randn((D,), dev, 22) * 0.1
+    eps = 1e-12
+    y32, mean, rstd = vf.layernorm_fwd(x, g, b, eps, out_dtype=torch.float32)
+    ref = F.layer_norm(x, (D,), g, b, eps)
+    assert rel(y32, ref) < 1e-6
+    assert rel(mean, x.mean(-1)) < 1e-6
+    y16, _, _ = vf.layernorm_fwd(x, g, b, eps, out_dtype=torch.bfloat16)
+    assert rel(y16, ref) < 4e-3
+    # backward
+    dy = randn((rows, D), dev, 23)
+    dres = randn((rows, D), dev, 24)
+    xx = x.clone().requires_grad_(True)
+    gg, bb = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xx, (D,), gg, bb, eps).backward(dy)
+    dx, dg, db = vf.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)
+    assert rel(dx, xx.grad + dres) < 1e-5
+    assert rel(dg, gg.grad) < 1e-5 and rel(db, bb.grad) < 1e-5
+    dx16, dg16, _ = vf.layernorm_bwd(bf(dy), x, g, mean, rstd)
+    xx.grad = None
+    gg.grad = None
+    F.layer_norm(xx, (D,), gg, bb, eps).backward(bf(dy).float())
+    assert rel(dx16, xx.grad) < 1e-5 and rel(dg16, gg.grad) < 1e-5
+
+
+def attn_ref(qkv, B, H, T, dh, scale, mask=None):
+    q, k, v = qkv.float().view(B, T, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = s.softmax(-1)
+    pd = p if mask is None else p * mask
+    ctx = (pd @ v).permute(0, 2, 1, 3).reshape(B * T, H * dh)
+    return ctx, p, torch.logsumexp(s, -1)
+
+
+ATT_SHAPES = [(2, 2, 129, 16), (2, 3, 5, 64), (2, 4, 197, 64), (1, 2, 300, 32), (1, 1, 70, 128), (1, 2, 64, 64), (1, 1, 577, 64)]
+
+
+@pytest.mark.parametrize("B,H,T,dh", ATT_SHAPES)
+def test_attention_fwd_bwd(dev, B, H, T, dh):
+    import vit_amd.functional as vf
+
+    scale = dh ** -0.5
+    qkv = bf(randn((B * T, 3 * H * dh), dev, 30))
+    ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, scale)
+    q32 = qkv.float().requires_grad_(True)
+    ref, p, lse_ref = attn_ref(q32, B, H, T, dh, scale)
+    assert rel(ctx, ref) < 6e-3
+    assert rel(lse, lse_ref.reshape(B * H, T)) < 1e-5
+    probs = vf.attention_probs(qkv, B, H, T, dh, scale)
+    assert rel(probs, p) < 1e-5
+    dctx = bf(randn((B * T, H * dh), dev, 31))
+    ref.backward(dctx.float())
+    dqkv = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale)
+    g = q32.grad.view(B * T, 3, H * dh)
+    d = dqkv.float().view(B * T, 3, H * dh)
+    for i, nm in enumerate("qkv"):
+        assert rel(d[:, i], g[:, i]) < 1.5e-2, (nm, rel(d[:, i], g[:, i]))
+
+
+def extract_attn_mask(vf, dev, B, H, T, dh, drop):
+    """Recover the dropout multiplier M[b,h,q,k] of the attention kernel: with Q=K=0 the probabilities are 1/T, and a
+    one-hot V block makes ctx[q, d] = M[q, i*dh+d] / T."""
+    mask = torch.zeros((B, H, T, T), device=dev)
+    for i in range(math.ceil(T / dh)):
+        qkv = torch.zeros((B, T, 3, H, dh), device=dev)
+        for d in range(dh):
+            k = i * dh + d
+            if k < T:
+                qkv[:, k, 2, :, d] = 1.0
+        ctx, _ = vf.attention_fwd(bf(qkv.view(B * T, 3 * H * dh)), B, H, T, dh, 1.0, dropout=drop)
+        c = ctx.float().view(B, T, H, dh).permute(0, 2, 1, 3) * T   # [B,H,T(q),dh]
+        n = min(dh, T - i * dh)
+        mask[:, :, :, i * dh:i * dh + n] = c[..., :n]
+    return mask
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (1, 3, 197, 64)])
+def test_attention_dropout(dev, B, H, T, dh):
+    import vit_amd.functional as vf
+
+    drop = (0.1, 99, 3)
+    scale = dh ** -0.5
+    mask = extract_attn_mask(vf, dev, B, H, T, dh, drop)
+    vals = torch.unique(mask.round(decimals=2))
+    assert vals.numel() == 2 and abs(vals[1].item() - 1 / 0.9) < 2e-2, vals
+    mask = (mask > 0.5).float() * (65536.0 / (65536 - 6554))
+    assert abs((mask > 0).float().mean().item() - 0.9) < 0.01
+    qkv = bf(randn((B * T, 3 * H * dh), dev, 32))
+    ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, scale, dropout=drop)
+    q32 = qkv.float().requires_grad_(True)
+    ref, _, _ = attn_ref(q32, B, H, T, dh, scale, mask)
+    assert rel(ctx, ref) < 6e-3
+    dctx = bf(randn((B * T, H * dh), dev, 33))
+    ref.backward(dctx.float())
+    dqkv = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale, dropout=drop)
+    g = q32.grad.view(B * T, 3, H * dh)
+    d = dqkv.float().view(B * T, 3, H * dh)
+    for i in range(3):
+        assert rel(d[:, i], g[:, i]) < 1.5e-2, (i, rel(d[:, i], g[:, i]))
+
+
+def test_unfold_and_embed(dev):
+    import vit_amd.functional as vf
+
+    B, L, P, S = 3, 1000, 64, 48
+    N = math.ceil((L - P) / S) + 1
+    x = randn((B, L), dev, 40)
+    patches = vf.unfold_cast(x, P, S, N)
+    ref = x.unfold(1, P, S)
+    ref = torch.cat([ref, torch.zeros(B, N - ref.size(1), P, device=dev)], 1).reshape(B * N, P)
+    # the reference zero-pads a whole missing patch; a partially covered tail does not occur with unfold semantics
+    assert torch.equal(patches.float(), bf(ref).float())
+    D, T = 64, N + 1
+    tok = randn((B, T, D), dev, 41)
+    cls, pos = randn((D,), dev, 42), randn((T, D), dev, 43)
+    out = vf.embed_finish(tok.clone(), cls, pos)
+    exp = tok.clone()
+    exp[:, 0] = cls
+    exp = exp + pos
+    assert rel(out, exp) < 1e-7
+    drop = (0.1, 5, 1)
+    outd = vf.embed_finish(tok.clone(), cls, pos, dropout=drop)
+    m = (outd != 0).float()
+    assert abs(m.mean().item() - 0.9) < 0.02
+    assert rel(outd, exp * m * (65536.0 / (65536 - 6554))) < 1e-6
+    # backward
+    dtok = randn((B, T, D), dev, 44)
+    dcls = torch.empty(D, device=dev)
+    dpos = torch.empty((T, D), device=dev)
+    dpatch = vf.embed_finish_bwd(dtok, dcls, dpos, dropout=drop)
+    gm = dtok * m * (65536.0 / (65536 - 6554))
+    assert rel(dcls, gm[:, 0].sum(0)) < 1e-6
+    assert rel(dpos, gm.sum(0)) < 1e-6
+    assert rel(dpatch, gm[:, 1:].reshape(B * N, D)) < 4e-3
+
+
+def test_colsum_cast_dropout_bwd(dev):
+    import vit_amd.functional as vf
+
+    a = randn((1234, 768), dev, 50)
+    assert rel(vf.colsum(a), a.sum(0)) < 1e-5
+    a16 = bf(a)
+    assert rel(vf.colsum(a16), a16.float().sum(0)) < 1e-5
+    out = vf.colsum(a16, out=torch.ones(768, device=dev), accumulate=True)
+    assert rel(out, a16.float().sum(0) + 1) < 1e-5
+    assert torch.equal(vf.cast_f32_bf16(a), a16)
+    odd = randn((1003,), dev, 51)
+    assert torch.equal(vf.cast_f32_bf16(odd), bf(odd))
+    dy = vf.dropout_bwd_cast(a, (0.0, 0, 0))
+    assert torch.equal(dy, a16)
+
+
+@pytest.mark.parametrize("kind,C", [("mse", 1), ("l1", 3), ("ce", 5)])
+def test_head_loss(dev, kind, C):
+    import vit_amd.functional as vf
+    from vit_amd._cabi import LOSS_CE, LOSS_L1, LOSS_MSE
+
+    B, T, D = 37, 6, 192
+    last = randn((B, T, D), dev, 60)
+    W, b = randn((C, D), dev, 61, 0.1), randn((C,), dev, 62, 0.1)
+    if kind == "ce":
+        labels = torch.randint(0, C, (B,), device=dev)
+        code = LOSS_CE
+    else:
+        labels = torch.rand((B, C) if C > 1 else (B,), device=dev)
+        code = LOSS_L1 if kind == "l1" else LOSS_MSE
+    logits, loss = vf.head_loss_fwd(last, W, b, labels, code)
+    l32 = last.clone().requires_grad_(True)
+    W32, b32 = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lg = F.linear(l32[:, 0], W32, b32)
+    if kind == "ce":
+        ref = F.cross_entropy(lg, labels)
+    elif kind == "l1":
+        ref = F.l1_loss(lg.view(-1), labels.view(-1))
+    else:
+        ref = F.mse_loss(lg.view(-1), labels.view(-1))
+    assert rel(logits, lg) < 1e-5 and abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    (ref * 1.7).backward()
+    dloss = torch.full((1,), 1.7, device=dev)
+    dlast, dW, db = vf.head_loss_bwd(last, W, logits, labels, dloss, code)
+    assert rel(dlast, l32.grad) < 1e-5 and rel(dW, W32.grad) < 1e-5 and rel(db, b32.grad) < 1e-5
+
+
+def test_sqnorm_adamw(dev):
+    import vit_amd.functional as vf
+
+    n = 1_000_003
+    p0, g = randn((n,), dev, 70), randn((n,), dev, 71, 0.01)
+    sq = vf.grad_sqnorm(g)
+    assert abs(sq.item() - float((g.double() ** 2).sum())) < 1e-4 * sq.item()
+    # against torch.optim.AdamW with clip_grad_norm_(0.5)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for step in range(1, 4):
+        gs = g * step
+        pt.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 0.5)
+        opt.step()
+        sq = vf.grad_sqnorm(gs)
+        vf.adamw_step(p, gs, m, v, pb, lr=1e-3, weight_decay=0.01, step=step, sqnorm=sq, max_norm=0.5)
+        assert rel(p, pt.detach()) < 1e-6
+    assert torch.equal(pb, bf(p))

@@ -1,0 +1,72 @@
+// Handle, error string and workspace plumbing of libvit_amd.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+struct vit_ctx {
+  int device;
+  void* ws;
+  size_t ws_bytes;
+};
+
+namespace vit {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+void* ctx_workspace(vit_handle h, size_t* bytes) {
+  if (!h) {
+    *bytes = 0;
+    return nullptr;
+  }
+  *bytes = h->ws_bytes;
+  return h->ws;
+}
+
+}  // namespace vit
+
+extern "C" {
+
+int vit_version(void) { return VIT_AMD_VERSION; }
+
+const char* vit_last_error(void) { return vit::g_err; }
+
+int vit_create(vit_handle* out, int device) {
+  VIT_CHECK(out, VIT_ERR_ARG, "vit_create: null out pointer");
+  int n = 0;
+  VIT_HIP(hipGetDeviceCount(&n));
+  VIT_CHECK(device >= 0 && device < n, VIT_ERR_ARG, "vit_create: device %d out of range (%d visible)", device, n);
+  hipDeviceProp_t prop;
+  VIT_HIP(hipGetDeviceProperties(&prop, device));
+  VIT_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0, VIT_ERR_UNSUPPORTED,
+            "vit_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  vit_ctx* c = new vit_ctx();
+  c->device = device;
+  c->ws = nullptr;
+  c->ws_bytes = 0;
+  *out = c;
+  return VIT_OK;
+}
+
+int vit_destroy(vit_handle h) {
+  delete h;
+  return VIT_OK;
+}
+
+int vit_set_workspace(vit_handle h, void* ws, size_t bytes) {
+  VIT_CHECK(h, VIT_ERR_ARG, "vit_set_workspace: null handle");
+  VIT_CHECK(((uintptr_t)ws & 255) == 0, VIT_ERR_ARG, "vit_set_workspace: workspace must be 256-byte aligned");
+  h->ws = ws;
+  h->ws_bytes = bytes;
+  return VIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,517 @@
+// Fused softmax attention (forward + backward) for gfx950, flash-style: scores / probabilities never reach HBM.
+//
+// Reads Q, K, V straight out of the fused QKV projection's output [B*T, 3*H*dh] (token-major, head h at columns
+// h*dh of each third) and writes the merged-head context [B*T, H*dh], so no head split / merge copies exist.
+//
+// One wave owns 16 query rows (forward, dQ) or 16 keys (dK/dV); 4 waves share the 64-row K/V (or Q/dO) tiles staged
+// in LDS.  All MFMAs (v_mfma_f32_16x16x32_bf16) are issued "swapped" so the 16 owned rows sit on lane&15:
+//     S^T = K * Q^T,   O^T = V^T * P^T,   dP^T = V * dO^T,   dQ^T = K^T * dS^T          (owner = query)
+//     S   = Q * K^T,   dP  = dO * V^T,    dV^T = dO^T * P,   dK^T = Q^T * dS            (owner = key)
+// With that orientation (a) the softmax statistics m, l, lse, delta of a row live in the lane that owns the row
+// (only the 4 lane groups lane>>4 have to be combined: two xor-shuffles), (b) the P / dS accumulator tile is already
+// the B operand of the next MFMA (4 consecutive reduction indices per 16-tile per lane: k-slot j<4 -> tile 2u,
+// j>=4 -> tile 2u+1), and (c) the other operand of that product is a transposed read of the row-major LDS tile
+// (ds_read_b64_tr_b16) with the same slot order.  No P round trip through LDS, no permutes.
+//
+// LDS tile image: [64 rows][DH] bf16, 16-byte chunk c of row r at r*2*DH + ((c ^ swz(r)) << 4); row fragments by
+// ds_read_b128, transposed fragments by ds_read_b64_tr_b16 inside the chunks.
+#include <algorithm>
+#include <math.h>
+
+#include "common.h"
+
+namespace vit {
+
+constexpr int AW = 4;    // waves per workgroup
+constexpr int RT = 64;   // rows per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnArgs {
+  const short* qkv; short* ctx; float* lse;
+  const short* dctx; const float* delta; short* dqkv;
+  int B, H, T, dh;
+  float scale;
+  DropCfg drop;
+};
+
+template <int DH>
+__device__ __forceinline__ int swz(int r) {
+  return DH == 32 ? ((r >> 2) & 3) : (DH == 64 ? ((r >> 1) & 7) : (r & 15));
+}
+template <int DH>
+__device__ __forceinline__ int tile_off(int r, int c) {
+  return r * (DH * 2) + ((c ^ swz<DH>(r)) << 4);
+}
+
+// cooperative load of rows [row0, row0+64) x [0, DH) of a strided bf16 matrix into an LDS image (zero fill outside)
+template <int DH>
+__device__ __forceinline__ void load_tile(char* img, const short* g, long ld, int row0, int nrows, int dh, int tid) {
+  constexpr int CPR = DH / 8;
+#pragma unroll
+  for (int i = 0; i < (RT * CPR) / (AW * 64); ++i) {
+    const int q = tid + AW * 64 * i;
+    const int r = q / CPR, c = q % CPR;
+    const int row = row0 + r;
+    i32x4 v = {0, 0, 0, 0};
+    if (row < nrows && c * 8 < dh) v = *(const i32x4*)(g + (long)row * ld + c * 8);
+    *(i32x4*)(img + tile_off<DH>(r, c)) = v;
+  }
+}
+
+// 16 rows starting at rb (tile-local), reduction index = columns s*32 + 8*(lane>>4) + j
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_rows(const char* img, int rb, int s, int l15, int lg) {
+  return *(const bf16x8*)(img + tile_off<DH>(rb + l15, s * 4 + lg));
+}
+// transposed: MFMA rows = columns cb..cb+15 of the tile, reduction slots j<4 -> row rb0 + 4*lg + j, j>=4 -> rb1 + ...
+template <int DH>
+__device__ __forceinline__ bf16x8 frag_cols(const char* img, int rb0, int rb1, int cb, int l15, int lg) {
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int col = cb + 4 * tp;
+  const int c = col >> 3, half = (col >> 2) & 1;
+  const int r0 = rb0 + 4 * lg + tq, r1 = rb1 + 4 * lg + tq;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(img + tile_off<DH>(r0, c) + half * 8));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(img + tile_off<DH>(r1, c) + half * 8));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// the 16 rows a wave owns, straight from global memory into fragment registers (row = r0 + lane&15)
+template <int DH>
+__device__ __forceinline__ void load_own(bf16x8 (&f)[DH / 32], const short* g, long ld, int r0, int nrows, int dh,
+                                         int l15, int lg) {
+#pragma unroll
+  for (int s = 0; s < DH / 32; ++s) {
+    const int col = s * 32 + lg * 8;
+    i32x4 v = {0, 0, 0, 0};
+    if (r0 + l15 < nrows && col < dh) v = *(const i32x4*)(g + (long)(r0 + l15) * ld + col);
+    f[s] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  u32x4 r = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int DH>
+__global__ __launch_bounds__(AW * 64) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2];
+  char* Kimg = smem;
+  char* Vimg = smem + RT * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh;
+  const long ld = 3L * p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const int q0 = (blockIdx.x * AW + wave) * 16;
+
+  bf16x8 qf[DH / 32];
+  load_own<DH>(qf, qb, ld, q0, T, dh, l15, lg);
+  const float c = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.f;
+  f32x4 ot[DH / 16];
+#pragma unroll
+  for (int i = 0; i < DH / 16; ++i) ot[i] = zero4();
+  const unsigned long long drow = (unsigned long long)bh * T + (q0 + l15);
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+
+  for (int kb = 0; kb < T; kb += RT) {
+    if (kb) __syncthreads();
+    load_tile<DH>(Kimg, kb_, ld, kb, T, dh, tid);
+    load_tile<DH>(Vimg, vb, ld, kb, T, dh, tid);
+    __syncthreads();
+    f32x4 st[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j * 16 < T) {
+        f32x4 a = zero4();
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s)
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Kimg, j * 16, s, l15, lg), qf[s], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + j * 16 + lg * 4 + r;
+          a[r] = key < T ? a[r] * c : -INFINITY;
+          mx = fmaxf(mx, a[r]);
+        }
+        st[j] = a;
+      } else {
+        st[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[j][r] = exp2f(st[j][r] - mn);
+        ls += st[j][r];
+      }
+    l = l * alpha + ls;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) ot[i] *= alpha;
+    if (p.drop.thr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned key = kb + j * 16 + lg * 4;
+        float k0, k1, k2, k3;
+        drop_pair(p.drop, drow, half_cols, key, k0, k1);
+        drop_pair(p.drop, drow, half_cols, key + 2, k2, k3);
+        st[j][0] *= k0; st[j][1] *= k1; st[j][2] *= k2; st[j][3] *= k3;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb + u * 32 < T) {
+        const bf16x8 pf = pack8(st[2 * u], st[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt)
+          ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Vimg, u * 32, u * 32 + 16, dt * 16, l15, lg),
+                                                           pf, ot[dt], 0, 0, 0);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const int q = q0 + l15;
+  if (q < T) {
+    const float inv = 1.0f / l;
+    short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < dh) {
+        const f32x4 v = ot[dt] * inv;
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)(o + d) = pk;
+      }
+    }
+    if (lg == 0) p.lse[(long)bh * T + q] = (m + log2f(l)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta
+// delta[bh, q] = sum_d ctx[b, q, h, d] * dctx[b, q, h, d]; one thread per (row, head)
+__global__ void attn_delta_kernel(const short* __restrict__ ctx, const short* __restrict__ dctx,
+                                  float* __restrict__ delta, int B, int H, int T, int dh) {
+  const long n = (long)B * T * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const long row = i / H;  // b*T + q
+    const short* a = ctx + row * (H * dh) + h * dh;
+    const short* g = dctx + row * (H * dh) + h * dh;
+    float s = 0.f;
+    for (int d = 0; d < dh; d += 8) {
+      const bf16x8 x = *(const bf16x8*)(a + d), y = *(const bf16x8*)(g + d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += bf2f(x[k]) * bf2f(y[k]);
+    }
+    const long b = row / T, q = row - b * T;
+    delta[(b * H + h) * T + q] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <int DH>
+__global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2];
+  char* Kimg = smem;
+  char* Vimg = smem + RT * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh;
+  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  const int q0 = (blockIdx.x * AW + wave) * 16;
+  const int q = q0 + l15;
+
+  bf16x8 qf[DH / 32], dof[DH / 32];
+  load_own<DH>(qf, qb, ld, q0, T, dh, l15, lg);
+  load_own<DH>(dof, dob, ldc, q0, T, dh, l15, lg);
+  const float c = p.scale * LOG2E;
+  const float lse2 = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
+  const float del = q < T ? p.delta[(long)bh * T + q] : 0.f;
+  f32x4 dqt[DH / 16];
+#pragma unroll
+  for (int i = 0; i < DH / 16; ++i) dqt[i] = zero4();
+  const unsigned long long drow = (unsigned long long)bh * T + q;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+
+  for (int kb = 0; kb < T; kb += RT) {
+    if (kb) __syncthreads();
+    load_tile<DH>(Kimg, kb_, ld, kb, T, dh, tid);
+    load_tile<DH>(Vimg, vb, ld, kb, T, dh, tid);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ds[j] = zero4();
+      if (kb + j * 16 < T) {
+        f32x4 s_ = zero4(), dp = zero4();
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Kimg, j * 16, s, l15, lg), qf[s], s_, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Vimg, j * 16, s, l15, lg), dof[s], dp, 0, 0, 0);
+        }
+        const unsigned key0 = kb + j * 16 + lg * 4;
+        float k[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.drop.thr) {
+          drop_pair(p.drop, drow, half_cols, key0, k[0], k[1]);
+          drop_pair(p.drop, drow, half_cols, key0 + 2, k[2], k[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = ((int)key0 + r < T) ? exp2f(s_[r] * c - lse2) : 0.f;
+          ds[j][r] = pr * (dp[r] * k[r] - del);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb + u * 32 < T) {
+        const bf16x8 df = pack8(ds[2 * u], ds[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt)
+          dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Kimg, u * 32, u * 32 + 16, dt * 16, l15, lg),
+                                                            df, dqt[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (q < T) {
+    short* o = p.dqkv + ((long)b * T + q) * ld + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < dh) {
+        const f32x4 v = dqt[dt] * p.scale;
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)(o + d) = pk;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int DH>
+__global__ __launch_bounds__(AW * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2 + 2 * RT * 4];
+  char* Qimg = smem;
+  char* Oimg = smem + RT * DH * 2;
+  float* lse_s = (float*)(smem + 2 * RT * DH * 2);
+  float* del_s = lse_s + RT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh;
+  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  const int k0w = (blockIdx.x * AW + wave) * 16;
+  const int key = k0w + l15;
+
+  bf16x8 kf[DH / 32], vf[DH / 32];
+  load_own<DH>(kf, kb_, ld, k0w, T, dh, l15, lg);
+  load_own<DH>(vf, vb, ld, k0w, T, dh, l15, lg);
+  const float c = p.scale * LOG2E;
+  f32x4 dkt[DH / 16], dvt[DH / 16];
+#pragma unroll
+  for (int i = 0; i < DH / 16; ++i) dkt[i] = dvt[i] = zero4();
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+
+  for (int qb0 = 0; qb0 < T; qb0 += RT) {
+    if (qb0) __syncthreads();
+    load_tile<DH>(Qimg, qb, ld, qb0, T, dh, tid);
+    load_tile<DH>(Oimg, dob, ldc, qb0, T, dh, tid);
+    if (tid < RT) {
+      const int qq = qb0 + tid;
+      lse_s[tid] = qq < T ? p.lse[(long)bh * T + qq] * LOG2E : INFINITY;
+      del_s[tid] = qq < T ? p.delta[(long)bh * T + qq] : 0.f;
+    }
+    __syncthreads();
+    f32x4 pd[4], ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pd[j] = ds[j] = zero4();
+      if (qb0 + j * 16 < T) {
+        f32x4 s_ = zero4(), dp = zero4();
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          s_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Qimg, j * 16, s, l15, lg), kf[s], s_, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Oimg, j * 16, s, l15, lg), vf[s], dp, 0, 0, 0);
+        }
+        const f32x4 l4 = *(const f32x4*)(lse_s + j * 16 + lg * 4);
+        const f32x4 d4 = *(const f32x4*)(del_s + j * 16 + lg * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = exp2f(s_[r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
+          float mk = 1.f;
+          if (p.drop.thr) {
+            const unsigned long long row = (unsigned long long)bh * T + (qb0 + j * 16 + lg * 4 + r);
+            const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, row * half_cols + ((unsigned)key >> 1));
+            const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+            mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
+          }
+          pd[j][r] = pr * mk;
+          ds[j][r] = pr * (dp[r] * mk - d4[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (qb0 + u * 32 < T) {
+        const bf16x8 pf = pack8(pd[2 * u], pd[2 * u + 1]);
+        const bf16x8 df = pack8(ds[2 * u], ds[2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Oimg, u * 32, u * 32 + 16, dt * 16, l15, lg),
+                                                            pf, dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Qimg, u * 32, u * 32 + 16, dt * 16, l15, lg),
+                                                            df, dkt[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (key < T) {
+    short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * dh + h * dh;
+    short* ov = ok + p.H * dh;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const int d = dt * 16 + lg * 4;
+      if (d < dh) {
+        const f32x4 a = dkt[dt] * p.scale, v = dvt[dt];
+        u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+        u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)(ok + d) = pk;
+        *(u32x2*)(ov + d) = pv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ probabilities
+// eval-time attention maps [B,H,T,T] f32 (output_attentions=True, consumed by the reference's viz callbacks);
+// a plain VALU kernel off the training path: one wave per (b, h, q) row.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict__ qkv, float* __restrict__ probs, int B,
+                                                         int H, int T, int dh, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // (b*H + h)*T + q
+  if (row >= (long)B * H * T) return;
+  const int q = (int)(row % T);
+  const long bh = row / T;
+  const int h = (int)(bh % H);
+  const long b = bh / H;
+  const long ld = 3L * H * dh;
+  const short* qp = qkv + (b * T + q) * ld + h * dh;
+  const short* kp = qkv + b * T * ld + H * dh + h * dh;
+  float* out = probs + row * T;
+  float mx = -INFINITY;
+  for (int k = lane; k < T; k += 64) {
+    float s = 0.f;
+    for (int d = 0; d < dh; d += 8) {
+      const bf16x8 x = *(const bf16x8*)(qp + d), y = *(const bf16x8*)(kp + (long)k * ld + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
+    }
+    s *= scale;
+    out[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < T; k += 64) {
+    const float e = __expf(out[k] - mx);
+    out[k] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int k = lane; k < T; k += 64) out[k] *= inv;
+}
+
+static int check_attn(const char* fn, int B, int H, int T, int dh, float p) {
+  VIT_CHECK(B > 0 && H > 0 && T > 0 && dh > 0, VIT_ERR_ARG, "%s: B=%d H=%d T=%d dh=%d", fn, B, H, T, dh);
+  VIT_CHECK((dh % 8) == 0 && dh <= 128, VIT_ERR_UNSUPPORTED, "%s: head dim %d (need a multiple of 8, <= 128)", fn, dh);
+  VIT_CHECK(p >= 0.f && p < 1.f, VIT_ERR_ARG, "%s: dropout_p out of [0,1)", fn);
+  return VIT_OK;
+}
+
+#define DISPATCH_DH(KERNEL, grid, st, a)                                                         \
+  do {                                                                                           \
+    if (a.dh <= 32) hipLaunchKernelGGL((KERNEL<32>), grid, dim3(AW * 64), 0, st, a);              \
+    else if (a.dh <= 64) hipLaunchKernelGGL((KERNEL<64>), grid, dim3(AW * 64), 0, st, a);         \
+    else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(AW * 64), 0, st, a);                        \
+  } while (0)
+
+}  // namespace vit
+
+extern "C" {
+using namespace vit;
+
+int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int B, int H, int T, int dh, float scale,
+                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(qkv && ctx && lse, VIT_ERR_ARG, "vit_attention_fwd: null pointer");
+  int rc = check_attn("vit_attention_fwd", B, H, T, dh, dropout_p);
+  if (rc != VIT_OK) return rc;
+  AttnArgs a = {};
+  a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.lse = lse;
+  a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
+  a.drop = make_drop(dropout_p, seed, site);
+  dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
+  DISPATCH_DH(attn_fwd_kernel, grid, (hipStream_t)stream, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                      float* delta, void* dqkv, int B, int H, int T, int dh, float scale, float dropout_p,
+                      uint64_t seed, uint64_t site, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(qkv && ctx && dctx && lse && delta && dqkv, VIT_ERR_ARG, "vit_attention_bwd: null pointer");
+  int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
+  if (rc != VIT_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * T * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st,
+                     (const short*)ctx, (const short*)dctx, delta, B, H, T, dh);
+  VIT_LAUNCH_CHECK();
+  AttnArgs a = {};
+  a.qkv = (const short*)qkv; a.lse = const_cast<float*>(lse);
+  a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
+  a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
+  a.drop = make_drop(dropout_p, seed, site);
+  dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
+  DISPATCH_DH(attn_bwd_dq_kernel, grid, st, a);
+  VIT_LAUNCH_CHECK();
+  DISPATCH_DH(attn_bwd_dkv_kernel, grid, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int B, int H, int T, int dh, float scale,
+                        vit_stream stream) {
+  (void)h;
+  VIT_CHECK(qkv && probs, VIT_ERR_ARG, "vit_attention_probs: null pointer");
+  int rc = check_attn("vit_attention_probs", B, H, T, dh, 0.f);
+  if (rc != VIT_OK) return rc;
+  const long rows = (long)B * H * T;
+  hipLaunchKernelGGL(attn_probs_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const short*)qkv, probs, B, H, T, dh, scale);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+}  // extern "C"

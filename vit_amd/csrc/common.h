@@ -1,0 +1,127 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of vit_amd.
+// Wave = 64 lanes everywhere; bf16 MFMA 16x16x32; LDS images are XOR-swizzled per access kind.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vit_amd.h"
+
+namespace vit {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // MFMA A/B fragment (8 bf16 = 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;   // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define VIT_CHECK(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      ::vit::set_error(__VA_ARGS__);           \
+      return (code);                           \
+    }                                          \
+  } while (0)
+#define VIT_HIP(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      ::vit::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return VIT_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+#define VIT_LAUNCH_CHECK() VIT_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(short h) {
+  return __builtin_bit_cast(float, ((unsigned)(unsigned short)h) << 16);
+}
+__device__ __forceinline__ short f2bf(float f) {  // RNE; lowers to v_cvt_pk_bf16_f32 on gfx950, keeps NaN a NaN
+  return __builtin_bit_cast(short, (__bf16)f);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  f2 v = {lo, hi};
+  bf2 r = __builtin_convertvector(v, bf2);
+  return __builtin_bit_cast(unsigned, r);
+}
+
+// ---- dropout: counter-based, stateless, identical in every kernel that needs the same mask -----------
+// One 32-bit hash per PAIR of adjacent columns: element (row, col) of a [rows, ncols] tensor (ncols even) draws
+// the low (col even) or high (col odd) 16 bits of hash(row * ncols/2 + col/2).  keep <=> r16 >= thr,
+// thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr) so the mask is exactly unbiased.
+// The reference's own masks come from torch's Philox stream and are implementation-defined (they differ between
+// its CPU and CUDA runs too), so only the distribution is part of the contract.
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned drop_hash(unsigned k0, unsigned k1, unsigned long long pair_idx) {
+  unsigned lo = (unsigned)pair_idx, hi = (unsigned)(pair_idx >> 32);
+  unsigned x = lowbias32(lo ^ k0);
+  x ^= k1 + hi * 0x9E3779B9u;
+  return lowbias32(x);
+}
+struct DropCfg {
+  unsigned thr;   // 0 => dropout off
+  float scale;    // 1/(1-p_eff)
+  unsigned k0, k1;
+};
+__host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint64_t site) {
+  DropCfg d;
+  unsigned thr = (p <= 0.f) ? 0u : (unsigned)(p * 65536.0f + 0.5f);
+  if (thr > 65535u) thr = 65535u;
+  d.thr = thr;
+  d.scale = 65536.0f / (float)(65536u - thr);
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (site + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  d.k0 = (unsigned)z;
+  d.k1 = (unsigned)(z >> 32);
+  return d;
+}
+// multiplier (0 or scale) for 2 adjacent columns starting at even column `col`
+__device__ __forceinline__ void drop_pair(const DropCfg& d, unsigned long long row, unsigned half_cols, unsigned col,
+                                          float& m0, float& m1) {
+  unsigned h = drop_hash(d.k0, d.k1, row * half_cols + (col >> 1));
+  m0 = ((h & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
+  m1 = ((h >> 16) >= d.thr) ? d.scale : 0.f;
+}
+
+// ---- exact-erf GELU (HF hidden_act="gelu", src/models/builder.py:246) ---------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- raw buffer resources: hardware bounds check, out-of-range lanes read 0 --------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned long long bytes) {
+  unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+constexpr unsigned OOB = 0x80000000u;  // any voffset >= num_records reads as zero
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace vit

@@ -1,0 +1,479 @@
+// HBM-bound side kernels of the ViT step for gfx950: unfold+cast, embedding finish (CLS / pos-emb / dropout) and its
+// backward, dropout-backward cast, deterministic column sums (bias gradients), head + loss, global grad norm, AdamW.
+// All are vectorised (8-16 B per lane), grid-stride, and free of float atomics (reference: deterministic=True).
+#include <algorithm>
+
+#include "common.h"
+
+namespace vit {
+
+void* ctx_workspace(vit_handle h, size_t* bytes);
+
+static inline int grid_for(long n, int block = 256, int cap = 4096) {
+  return (int)std::max<long>(1, std::min<long>((n + block - 1) / block, cap));
+}
+
+// ------------------------------------------------------------------------------------------ unfold + cast
+// patches[(b*N+n)*P + p] = bf16(x[b*L + n*S + p]); a window that does not fit entirely inside the signal is ALL zero:
+// Tensor.unfold drops partial windows and the reference appends whole zero patches (tokenization.py:45-49)
+__global__ void unfold_cast_kernel(const float* __restrict__ x, short* __restrict__ out, int B, int L, int P, int S,
+                                   int N) {
+  const long total = (long)B * N * (P >> 2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int pv = (int)(i % (P >> 2)) << 2;
+    const long bn = i / (P >> 2);
+    const int n = (int)(bn % N);
+    const long b = bn / N;
+    const int pos = n * S + pv;
+    const float* src = x + b * L + pos;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (n * S + P <= L) ? src[k] : 0.f;
+    u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(u32x2*)(out + bn * P + pv) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ embedding finish
+__global__ void embed_finish_kernel(float* __restrict__ tok, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, int B, int T, int D, DropCfg drop) {
+  const int dv = D >> 2;
+  const long total = (long)B * T * dv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dv) << 2;
+    const long row = i / dv;  // b*T + t
+    const int t = (int)(row % T);
+    float* p = tok + row * D + d;
+    f32x4 v = (t == 0) ? *(const f32x4*)(cls + d) : *(const f32x4*)p;
+    if (pos) v += *(const f32x4*)(pos + (long)t * D + d);
+    if (drop.thr) {
+      float k0, k1, k2, k3;
+      drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)d, k0, k1);
+      drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)d + 2, k2, k3);
+      v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+    }
+    *(f32x4*)p = v;
+  }
+}
+
+// one thread per (t, 4 columns): walks the batch, applies the embedding-dropout mask, emits the bf16 gradient of the
+// patch projection output (rows t >= 1) and the batch-summed gradients of cls_token (t == 0) / position_embeddings.
+__global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, short* __restrict__ dpatch,
+                                        float* __restrict__ dcls, float* __restrict__ dpos, int B, int T, int D,
+                                        DropCfg drop, int accumulate) {
+  const int dv = D >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * dv) return;
+  const int d = (i % dv) << 2;
+  const int t = i / dv;
+  const int N = T - 1;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const long row = (long)b * T + t;
+    f32x4 v = *(const f32x4*)(dtok + row * D + d);
+    if (drop.thr) {
+      float k0, k1, k2, k3;
+      drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)d, k0, k1);
+      drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)d + 2, k2, k3);
+      v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+    }
+    acc += v;
+    if (t > 0) {
+      u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)(dpatch + ((long)b * N + (t - 1)) * D + d) = pk;
+    }
+  }
+  if (t == 0) {
+    f32x4 o = acc;
+    if (accumulate) o += *(const f32x4*)(dcls + d);
+    *(f32x4*)(dcls + d) = o;
+  }
+  if (dpos) {
+    f32x4 o = acc;
+    if (accumulate) o += *(const f32x4*)(dpos + (long)t * D + d);
+    *(f32x4*)(dpos + (long)t * D + d) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dropout bwd + cast
+__global__ void dropout_bwd_cast_kernel(const float* __restrict__ dx, short* __restrict__ dy, long rows, int cols,
+                                        DropCfg drop) {
+  const int cv = cols >> 2;
+  const long total = rows * cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) << 2;
+    const long row = i / cv;
+    f32x4 v = *(const f32x4*)(dx + row * cols + c);
+    if (drop.thr) {
+      float k0, k1, k2, k3;
+      drop_pair(drop, (unsigned long long)row, (unsigned)(cols >> 1), (unsigned)c, k0, k1);
+      drop_pair(drop, (unsigned long long)row, (unsigned)(cols >> 1), (unsigned)c + 2, k2, k3);
+      v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+    }
+    u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(u32x2*)(dy + row * cols + c) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ column sums
+// stage 1: block (64 x 4): 64 lanes x 4 columns each = 256 columns, 4 row-lanes; grid.y row chunks
+template <int BF16>
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restrict__ a, long lda, float* __restrict__ part,
+                                                            int rows, int cols) {
+  __shared__ f32x4 red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + tx) << 2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    for (int r = blockIdx.y * 4 + ty; r < rows; r += gridDim.y * 4) {
+      if (BF16) {
+        bf16x4 t = *(const bf16x4*)((const short*)a + (long)r * lda + c);
+        acc += (f32x4){bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+      } else {
+        acc += *(const f32x4*)((const float*)a + (long)r * lda + c);
+      }
+    }
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    f32x4 s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    *(f32x4*)(part + (long)blockIdx.y * cols + c) = s;
+  }
+}
+__global__ void colsum_stage2_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int cols,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int k = 0; k < nchunk; ++k) a += part[(long)k * cols + c];
+  if (accumulate) a += out[c];
+  out[c] = a;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, short* __restrict__ dst, long n) {
+  const long nv = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = *(const f32x4*)(src + 4 * i);
+    u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *(u32x2*)(dst + 4 * i) = pk;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nv << 2) + threadIdx.x] = f2bf(src[(nv << 2) + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------ head + loss
+// one wave per sample: logits[b, c] = <last_hidden[b, 0, :], W[c, :]> + bias[c]
+__global__ __launch_bounds__(64) void head_logits_kernel(const float* __restrict__ last, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ logits,
+                                                         int T, int D, int C) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* x = last + (long)b * T * D;
+  for (int c = 0; c < C; ++c) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += x[d] * W[(long)c * D + d];
+    s = wave_sum(s);
+    if (lane == 0) logits[(long)b * C + c] = s + bias[c];
+  }
+}
+// single block: mean loss over the batch (fixed summation order)
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ logits, const void* __restrict__ labels,
+                                                   float* __restrict__ loss, int B, int C, int kind) {
+  __shared__ float red[256];
+  float a = 0.f;
+  if (kind == VIT_LOSS_CE) {
+    const long long* lab = (const long long*)labels;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const float* z = logits + (long)b * C;
+      float mx = z[0];
+      for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) se += __expf(z[c] - mx);
+      a += (mx + __logf(se)) - z[lab[b]];
+    }
+  } else {
+    const float* lab = (const float*)labels;
+    for (int i = threadIdx.x; i < B * C; i += 256) {
+      const float d = logits[i] - lab[i];
+      a += (kind == VIT_LOSS_L1) ? fabsf(d) : d * d;
+    }
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)(kind == VIT_LOSS_CE ? B : B * C);
+}
+// dlogits (workspace, [B,C]) and the CLS rows of d(last_hidden); one wave per sample
+__global__ __launch_bounds__(64) void head_bwd_rows_kernel(const float* __restrict__ W, const float* __restrict__ logits,
+                                                           const void* __restrict__ labels,
+                                                           const float* __restrict__ dloss, float* __restrict__ dlogits,
+                                                           float* __restrict__ dlast, int B, int T, int D, int C,
+                                                           int kind) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float up = dloss[0];
+  const float* z = logits + (long)b * C;
+  float mx = 0.f, se = 1.f;
+  if (kind == VIT_LOSS_CE) {
+    mx = z[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(z[c] - mx);
+  }
+  for (int c = 0; c < C; ++c) {
+    float g;
+    if (kind == VIT_LOSS_CE) {
+      const long long y = ((const long long*)labels)[b];
+      g = (__expf(z[c] - mx) / se - (c == y ? 1.f : 0.f)) / (float)B;
+    } else {
+      const float d = z[c] - ((const float*)labels)[(long)b * C + c];
+      g = (kind == VIT_LOSS_L1) ? ((d > 0.f) - (d < 0.f)) / (float)(B * C) : 2.f * d / (float)(B * C);
+    }
+    g *= up;
+    if (lane == 0) dlogits[(long)b * C + c] = g;
+    for (int d = lane; d < D; d += 64) {
+      float* o = dlast + (long)b * T * D + d;
+      *o = (c == 0 ? 0.f : *o) + g * W[(long)c * D + d];
+    }
+  }
+}
+// dW[c, d] = sum_b dlogits[b,c] * cls[b,d];  db[c] = sum_b dlogits[b,c]
+__global__ void head_bwd_params_kernel(const float* __restrict__ last, const float* __restrict__ dlogits,
+                                       float* __restrict__ dW, float* __restrict__ db, int B, int T, int D, int C,
+                                       int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * D) {
+    const int c = i / D, d = i - c * D;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dlogits[(long)b * C + c] * last[(long)b * T * D + d];
+    if (accumulate) a += dW[i];
+    dW[i] = a;
+  }
+  if (i < C) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dlogits[(long)b * C + i];
+    if (accumulate) a += db[i];
+    db[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ grad norm + AdamW
+__global__ __launch_bounds__(256) void sqnorm_stage1_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  const long nv = n >> 2;
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = *(const f32x4*)(g + 4 * i);
+    a += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(nv << 2) + threadIdx.x];
+    a += v * v;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sqnorm_stage2_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) a += part[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m,v EMA; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    short* __restrict__ pb, long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float rsqrt_bc2,
+                                                    const float* __restrict__ sqnorm, float max_norm) {
+  float clip = 1.f;
+  if (sqnorm) clip = fminf(1.f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));
+  const float step = lr / bc1, decay = 1.f - lr * wd;
+  const long nv = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = *(const f32x4*)(p + 4 * i);
+    const f32x4 gg = *(const f32x4*)(g + 4 * i) * clip;
+    f32x4 mm = *(const f32x4*)(m + 4 * i);
+    f32x4 vv = *(const f32x4*)(v + 4 * i);
+    mm = mm * b1 + gg * (1.f - b1);
+    vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pp[k] = pp[k] * decay - step * mm[k] / (sqrtf(vv[k]) * rsqrt_bc2 + eps);
+    *(f32x4*)(p + 4 * i) = pp;
+    *(f32x4*)(m + 4 * i) = mm;
+    *(f32x4*)(v + 4 * i) = vv;
+    if (pb) {
+      u32x2 pk = {pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
+      *(u32x2*)(pb + 4 * i) = pk;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (nv << 2) + threadIdx.x;
+    const float gg = g[i] * clip;
+    const float mm = m[i] * b1 + gg * (1.f - b1);
+    const float vv = v[i] * b2 + gg * gg * (1.f - b2);
+    const float pp = p[i] * decay - step * mm / (sqrtf(vv) * rsqrt_bc2 + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f2bf(pp);
+  }
+}
+
+}  // namespace vit
+
+extern "C" {
+using namespace vit;
+
+int vit_unfold_cast(vit_handle h, const float* x, void* patches, int B, int L, int P, int S, int N, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(x && patches, VIT_ERR_ARG, "vit_unfold_cast: null pointer");
+  VIT_CHECK(B > 0 && L > 0 && P > 0 && S > 0 && N > 0 && (P % 4) == 0, VIT_ERR_ARG,
+            "vit_unfold_cast: B=%d L=%d P=%d S=%d N=%d (P must be a multiple of 4)", B, L, P, S, N);
+  VIT_CHECK((long)(N - 1) * S < L, VIT_ERR_ARG, "vit_unfold_cast: patch %d starts past the signal", N - 1);
+  const long total = (long)B * N * (P / 4);
+  hipLaunchKernelGGL(unfold_cast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (short*)patches, B,
+                     L, P, S, N);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float* pos, int B, int T, int D,
+                     float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(tokens && cls, VIT_ERR_ARG, "vit_embed_finish: null pointer");
+  VIT_CHECK(B > 0 && T > 1 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_embed_finish: B=%d T=%d D=%d", B, T, D);
+  VIT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, VIT_ERR_ARG, "vit_embed_finish: dropout_p out of [0,1)");
+  const long total = (long)B * T * (D / 4);
+  hipLaunchKernelGGL(embed_finish_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tokens, cls, pos, B,
+                     T, D, make_drop(dropout_p, seed, site));
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, float* dcls, float* dpos, int B, int T,
+                         int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(dtokens && dpatch_out && dcls, VIT_ERR_ARG, "vit_embed_finish_bwd: null pointer");
+  VIT_CHECK(B > 0 && T > 1 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_embed_finish_bwd: B=%d T=%d D=%d", B, T, D);
+  hipLaunchKernelGGL(embed_finish_bwd_kernel, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     dtokens, (short*)dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int rows, int cols, float dropout_p, uint64_t seed,
+                         uint64_t site, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(dx && dy, VIT_ERR_ARG, "vit_dropout_bwd_cast: null pointer");
+  VIT_CHECK(rows > 0 && cols > 0 && (cols % 4) == 0, VIT_ERR_ARG, "vit_dropout_bwd_cast: rows=%d cols=%d", rows, cols);
+  const long total = (long)rows * (cols / 4);
+  hipLaunchKernelGGL(dropout_bwd_cast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, (short*)dy,
+                     (long)rows, cols, make_drop(dropout_p, seed, site));
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_colsum(vit_handle h, const void* a, int a_dtype, int64_t lda, float* out, int rows, int cols, int accumulate,
+               vit_stream stream) {
+  VIT_CHECK(a && out, VIT_ERR_ARG, "vit_colsum: null pointer");
+  VIT_CHECK(rows > 0 && cols > 0 && (cols % 4) == 0 && (lda % 4) == 0 && lda >= cols, VIT_ERR_ARG,
+            "vit_colsum: rows=%d cols=%d lda=%ld", rows, cols, (long)lda);
+  const int gx = cdiv(cols, 256);
+  const int gy = std::max(1, std::min(cdiv(rows, 64), 2048 / gx));
+  size_t wsb = 0;
+  float* part = (float*)ctx_workspace(h, &wsb);
+  const size_t need = (size_t)gy * cols * sizeof(float);
+  VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_colsum: needs %zu workspace bytes, have %zu", need, wsb);
+  hipStream_t st = (hipStream_t)stream;
+  if (a_dtype == VIT_BF16)
+    hipLaunchKernelGGL(colsum_stage1_kernel<1>, dim3(gx, gy), dim3(256), 0, st, a, (long)lda, part, rows, cols);
+  else
+    hipLaunchKernelGGL(colsum_stage1_kernel<0>, dim3(gx, gy), dim3(256), 0, st, a, (long)lda, part, rows, cols);
+  VIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, part, out, gy, cols, accumulate);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_cast_f32_bf16(vit_handle h, const float* src, void* dst, int64_t n, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(src && dst && n > 0, VIT_ERR_ARG, "vit_cast_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, (short*)dst,
+                     (long)n);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_head_loss_fwd(vit_handle h, const float* last_hidden, const float* W, const float* b, const void* labels,
+                      float* logits, float* loss_out, int B, int T, int D, int C, int loss_kind, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(last_hidden && W && b && logits, VIT_ERR_ARG, "vit_head_loss_fwd: null pointer");
+  VIT_CHECK(B > 0 && T > 0 && D > 0 && C > 0, VIT_ERR_ARG, "vit_head_loss_fwd: B=%d T=%d D=%d C=%d", B, T, D, C);
+  VIT_CHECK(loss_kind >= VIT_LOSS_MSE && loss_kind <= VIT_LOSS_CE, VIT_ERR_ARG, "vit_head_loss_fwd: bad loss_kind");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_logits_kernel, dim3(B), dim3(64), 0, st, last_hidden, W, b, logits, T, D, C);
+  VIT_LAUNCH_CHECK();
+  if (labels) {
+    VIT_CHECK(loss_out, VIT_ERR_ARG, "vit_head_loss_fwd: labels without loss_out");
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, logits, labels, loss_out, B, C, loss_kind);
+    VIT_LAUNCH_CHECK();
+  }
+  return VIT_OK;
+}
+
+int vit_head_loss_bwd(vit_handle h, const float* last_hidden, const float* W, const float* logits, const void* labels,
+                      const float* dloss, float* dlast_hidden, float* dW, float* db, int B, int T, int D, int C,
+                      int loss_kind, int accumulate, vit_stream stream) {
+  VIT_CHECK(last_hidden && W && logits && labels && dloss && dlast_hidden && dW && db, VIT_ERR_ARG,
+            "vit_head_loss_bwd: null pointer");
+  VIT_CHECK(B > 0 && T > 0 && D > 0 && C > 0, VIT_ERR_ARG, "vit_head_loss_bwd: B=%d T=%d D=%d C=%d", B, T, D, C);
+  size_t wsb = 0;
+  float* dlog = (float*)ctx_workspace(h, &wsb);
+  VIT_CHECK(dlog && wsb >= (size_t)B * C * 4, VIT_ERR_WORKSPACE, "vit_head_loss_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  VIT_HIP(hipMemsetAsync(dlast_hidden, 0, (size_t)B * T * D * sizeof(float), st));
+  hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(B), dim3(64), 0, st, W, logits, labels, dloss, dlog, dlast_hidden, B, T,
+                     D, C, loss_kind);
+  VIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_bwd_params_kernel, dim3(cdiv((long)C * D, 256)), dim3(256), 0, st, last_hidden, dlog, dW, db,
+                     B, T, D, C, accumulate);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream) {
+  VIT_CHECK(g && out && n > 0, VIT_ERR_ARG, "vit_grad_sqnorm: bad arguments");
+  const int blocks = grid_for(n / 4 + 1, 256, 1024);
+  size_t wsb = 0;
+  float* part = (float*)ctx_workspace(h, &wsb);
+  VIT_CHECK(part && wsb >= (size_t)blocks * 4, VIT_ERR_WORKSPACE, "vit_grad_sqnorm: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(blocks), dim3(256), 0, st, g, (long)n, part);
+  VIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(256), 0, st, part, blocks, out);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_adamw_step(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* sqnorm,
+                   float max_norm, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(p && g && m && v && n > 0 && step >= 1, VIT_ERR_ARG, "vit_adamw_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (short*)p_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)(1.0 / sqrt(bc2)), sqnorm, max_norm);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+}  // extern "C"

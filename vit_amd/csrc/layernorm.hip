@@ -1,0 +1,226 @@
+// LayerNorm forward / backward for gfx950: HBM-bound row kernels, one wave (64 lanes) per row.
+// x is the fp32 residual stream; statistics, affine and the backward sums are fp32 (eps = 1e-12 is far below bf16
+// resolution: SURVEY.md section 7).  Rows stay in registers between the statistics and the normalisation, so x is
+// read from HBM exactly once per pass.  Cross-lane sums use wave shuffles (DPP/permute), no LDS.
+#include <algorithm>
+
+#include "common.h"
+
+namespace vit {
+
+void* ctx_workspace(vit_handle h, size_t* bytes);
+
+// NV = float4 chunks per lane held in registers; supports D <= 256*NV
+template <int NV, int OUT_BF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nvec = D >> 2;
+  const float invD = 1.0f / (float)D;
+  for (int row = wave; row < rows; row += nwaves) {
+    const float* xr = x + (long)row * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c < nvec) ? *(const f32x4*)(xr + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 d = v[i] - mu;
+        q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) * invD + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const f32x4 g = *(const f32x4*)(gamma + 4 * c);
+        const f32x4 b = *(const f32x4*)(beta + 4 * c);
+        const f32x4 o = (v[i] - mu) * rs * g + b;
+        if (OUT_BF16) {
+          u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(u32x2*)((short*)y + (long)row * D + 4 * c) = pk;
+        } else {
+          *(f32x4*)((float*)y + (long)row * D + 4 * c) = o;
+        }
+      }
+    }
+  }
+}
+
+// backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + dres,  g = dy*gamma, xhat = (x-mean)*rstd
+// per-wave running sums of dy*xhat (dgamma) and dy (dbeta) over the rows the wave visits; block-combined through LDS
+// and written as one partial row per block: part[blk][0][D] (dgamma), part[blk][1][D] (dbeta).
+template <int NV, int DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ part, int rows, int D) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nvec = D >> 2;
+  const float invD = 1.0f / (float)D;
+  f32x4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = wave; row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 d;
+        if (DY_BF16) {
+          bf16x4 t = *(const bf16x4*)((const short*)dy + (long)row * D + 4 * c);
+          d = (f32x4){bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        } else {
+          d = *(const f32x4*)((const float*)dy + (long)row * D + 4 * c);
+        }
+        xh[i] = (*(const f32x4*)(x + (long)row * D + 4 * c) - mu) * rs;
+        g[i] = d * gam[i];
+        dg[i] += d * xh[i];
+        db[i] += d;
+        s1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
+        const f32x4 t2 = g[i] * xh[i];
+        s2 += (t2[0] + t2[1]) + (t2[2] + t2[3]);
+      } else {
+        xh[i] = g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
+        if (dres) o += *(const f32x4*)(dres + (long)row * D + 4 * c);
+        *(f32x4*)(dx + (long)row * D + 4 * c) = o;
+      }
+    }
+  }
+  // block combine
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      *(f32x4*)(red + (wib * 2 + 0) * D + 4 * c) = dg[i];
+      *(f32x4*)(red + (wib * 2 + 1) * D + 4 * c) = db[i];
+    }
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
+    float a = 0.f;
+    for (int w = 0; w < nw; ++w) a += red[w * 2 * D + i];
+    part[(long)blockIdx.x * 2 * D + i] = a;
+  }
+}
+
+// out[c] (+)= sum_blk part[blk][c]; part rows have `width` floats
+__global__ void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
+                                   int nblk, int D, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * D) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[(long)b * 2 * D + i];
+  float* o = (i < D) ? (out0 + i) : (out1 + (i - D));
+  if (accumulate) a += *o;
+  *o = a;
+}
+
+template <int OUT_BF16>
+static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
+                           int D, float eps, hipStream_t st) {
+  const int blocks = std::min(cdiv(rows, 4), 2048);
+  const int nv = cdiv(D, 256);
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, OUT_BF16>), dim3(blocks), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, D, eps)
+  if (nv <= 1) LAUNCH(1);
+  else if (nv <= 2) LAUNCH(2);
+  else if (nv <= 3) LAUNCH(3);
+  else if (nv <= 4) LAUNCH(4);
+  else if (nv <= 8) LAUNCH(8);
+  else { set_error("vit_layernorm_fwd: D=%d > 2048 not supported", D); return VIT_ERR_UNSUPPORTED; }
+#undef LAUNCH
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+template <int DY_BF16>
+static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const float* mean, const float* rstd,
+                           const float* dres, float* dx, float* part, int rows, int D, int blocks, hipStream_t st) {
+  const int nv = cdiv(D, 256);
+  const size_t sh = (size_t)4 * 2 * D * sizeof(float);
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16>), dim3(blocks), dim3(256), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D)
+  if (nv <= 1) LAUNCH(1);
+  else if (nv <= 2) LAUNCH(2);
+  else if (nv <= 3) LAUNCH(3);
+  else if (nv <= 4) LAUNCH(4);
+  else if (nv <= 8) LAUNCH(8);
+  else { set_error("vit_layernorm_bwd: D=%d > 2048 not supported", D); return VIT_ERR_UNSUPPORTED; }
+#undef LAUNCH
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+}  // namespace vit
+
+extern "C" {
+
+int vit_layernorm_fwd(vit_handle h, const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int rows, int D, float eps, vit_stream stream) {
+  using namespace vit;
+  (void)h;
+  VIT_CHECK(x && gamma && beta && y, VIT_ERR_ARG, "vit_layernorm_fwd: null pointer");
+  VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_fwd: rows=%d D=%d (D must be a multiple of 4)", rows, D);
+  VIT_CHECK(y_dtype == VIT_BF16 || y_dtype == VIT_F32, VIT_ERR_ARG, "vit_layernorm_fwd: bad y_dtype");
+  hipStream_t st = (hipStream_t)stream;
+  return y_dtype == VIT_BF16 ? ln_fwd_dispatch<1>(x, gamma, beta, y, mean, rstd, rows, D, eps, st)
+                             : ln_fwd_dispatch<0>(x, gamma, beta, y, mean, rstd, rows, D, eps, st);
+}
+
+int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                      const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                      float* dbeta, int rows, int D, vit_stream stream) {
+  using namespace vit;
+  VIT_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, VIT_ERR_ARG, "vit_layernorm_bwd: null pointer");
+  VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd: rows=%d D=%d", rows, D);
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = std::min(cdiv(rows, 16), 512);
+  size_t wsb = 0;
+  float* part = (float*)ctx_workspace(h, &wsb);
+  const size_t need = (size_t)blocks * 2 * D * sizeof(float);
+  VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_layernorm_bwd: needs %zu workspace bytes, have %zu", need, wsb);
+  int rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st)
+                                : ln_bwd_dispatch<0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st);
+  if (rc != VIT_OK) return rc;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, st, part, dgamma, dbeta, blocks, D, 0);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI (include/vit_amd.h).  torch supplies device memory and the current HIP stream;
+every computation happens in libvit_amd.so.  No function here has a PyTorch / CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _cabi
+from ._cabi import ACT_DGELU, ACT_GELU, ACT_NONE, LOSS_CE, LOSS_L1, LOSS_MSE, VIT_BF16, VIT_F32, GemmDesc, check
+
+_DT = {torch.float32: VIT_F32, torch.bfloat16: VIT_BF16}
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _h(t: torch.Tensor) -> _cabi.Handle:
+    if not t.is_cuda:
+        raise _cabi.VitError("vit_amd kernels need tensors on an MI355X (cuda/hip device); there is no CPU path")
+    return _cabi.handle_for(t.device)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype:
+        raise _cabi.VitError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _cabi.VitError(f"{name}: tensor must be contiguous")
+
+
+Dropout = Tuple[float, int, int]  # (p, seed, site)
+NO_DROP: Dropout = (0.0, 0, 0)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: bool = False, b_trans: bool = False,
+         lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None,
+         out_dtype=torch.bfloat16, ldc: Optional[int] = None, alpha: float = 1.0, bias: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, aux_out: Optional[torch.Tensor] = None, aux_in: Optional[torch.Tensor] = None,
+         dropout: Dropout = NO_DROP, residual: Optional[torch.Tensor] = None, row_map: Tuple[int, int, int] = (0, 0, 0),
+         out_rows: Optional[int] = None, split_k: int = 0, accumulate: bool = False) -> torch.Tensor:
+    h = _h(a)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
+        raise _cabi.VitError("gemm: operands must be bf16")
+    if out is None:
+        out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a_trans, d.b_trans = int(a_trans), int(b_trans)
+    d.ab_dtype = VIT_BF16
+    d.A, d.lda = a.data_ptr(), lda if lda is not None else (M if a_trans else K)
+    d.B, d.ldb = b.data_ptr(), ldb if ldb is not None else (N if b_trans else K)
+    d.C, d.ldc, d.c_dtype = out.data_ptr(), ldc if ldc is not None else N, _DT[out.dtype]
+    d.alpha = alpha
+    d.bias = _ptr(bias)
+    d.act = act
+    d.aux_out, d.aux_in, d.ldaux = _ptr(aux_out), _ptr(aux_in), N
+    d.dropout_p, d.seed, d.site = dropout
+    d.residual, d.ldres = _ptr(residual), N
+    d.rows_per_batch, d.out_batch_rows, d.out_row_offset = row_map
+    d.split_k = split_k
+    d.accumulate = int(accumulate)
+    if split_k != 0 and split_k != 1:
+        h.ensure_workspace(64 * M * N * 4 if split_k < 0 else split_k * M * N * 4)
+    check(h.lib.vit_gemm(h.h, C.byref(d), _stream(a)), "vit_gemm")
+    return out
+
+
+def linear_fwd(x, W, bias=None, *, out_dtype=torch.bfloat16, act=ACT_NONE, aux_out=None, dropout: Dropout = NO_DROP,
+               residual=None, out=None):
+    M, K = x.shape
+    N = W.shape[0]
+    return gemm(x, W, M=M, N=N, K=K, out=out, out_dtype=out_dtype, bias=bias, act=act, aux_out=aux_out, dropout=dropout,
+                residual=residual)
+
+
+def linear_bwd_dx(dy, W, *, out_dtype=torch.bfloat16, dgelu_aux=None, out=None):
+    M, N = dy.shape
+    K = W.shape[1]
+    return gemm(dy, W, M=M, N=K, K=N, b_trans=True, out=out, out_dtype=out_dtype,
+                act=ACT_DGELU if dgelu_aux is not None else ACT_NONE, aux_in=dgelu_aux)
+
+
+def linear_bwd_dw(dy, x, *, out=None, accumulate=False):
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, x, M=N, N=K, K=M, a_trans=True, b_trans=True, out=out, out_dtype=torch.float32, split_k=-1,
+                accumulate=accumulate)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, out=None, want_stats: bool = True):
+    _chk(x, torch.float32, "layernorm_fwd x")
+    h = _h(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    check(h.lib.vit_layernorm_fwd(h.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _DT[y.dtype],
+                                  _ptr(mean), _ptr(rstd), rows, D, eps, _stream(x)), "vit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dx=None, dgamma=None, dbeta=None):
+    _chk(x, torch.float32, "layernorm_bwd x")
+    h = _h(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = dx if dx is not None else torch.empty_like(x)
+    dgamma = dgamma if dgamma is not None else torch.empty(D, dtype=torch.float32, device=x.device)
+    dbeta = dbeta if dbeta is not None else torch.empty(D, dtype=torch.float32, device=x.device)
+    check(h.lib.vit_layernorm_bwd(h.h, dy.data_ptr(), _DT[dy.dtype], x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                  rows, D, _stream(x)), "vit_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP, ctx=None, lse=None):
+    _chk(qkv, torch.bfloat16, "attention_fwd qkv")
+    h = _h(qkv)
+    ctx = ctx if ctx is not None else torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=qkv.device)
+    lse = lse if lse is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
+    p, seed, site = dropout
+    check(h.lib.vit_attention_fwd(h.h, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, H, T, dh, scale, p, seed, site,
+                                  _stream(qkv)), "vit_attention_fwd")
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, dctx, lse, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP,
+                  dqkv=None, delta=None):
+    _chk(qkv, torch.bfloat16, "attention_bwd qkv")
+    _chk(dctx, torch.bfloat16, "attention_bwd dctx")
+    h = _h(qkv)
+    dqkv = dqkv if dqkv is not None else torch.empty_like(qkv)
+    delta = delta if delta is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
+    p, seed, site = dropout
+    check(h.lib.vit_attention_bwd(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                  dqkv.data_ptr(), B, H, T, dh, scale, p, seed, site, _stream(qkv)), "vit_attention_bwd")
+    return dqkv
+
+
+def attention_probs(qkv, B: int, H: int, T: int, dh: int, scale: float):
+    _chk(qkv, torch.bfloat16, "attention_probs qkv")
+    h = _h(qkv)
+    probs = torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
+    check(h.lib.vit_attention_probs(h.h, qkv.data_ptr(), probs.data_ptr(), B, H, T, dh, scale, _stream(qkv)),
+          "vit_attention_probs")
+    return probs
+
+
+# ------------------------------------------------------------------------------------------------ embedding side
+def unfold_cast(x, P: int, S: int, N: int, out=None):
+    _chk(x, torch.float32, "unfold_cast x")
+    h = _h(x)
+    B, L = x.shape
+    out = out if out is not None else torch.empty((B * N, P), dtype=torch.bfloat16, device=x.device)
+    check(h.lib.vit_unfold_cast(h.h, x.data_ptr(), out.data_ptr(), B, L, P, S, N, _stream(x)), "vit_unfold_cast")
+    return out
+
+
+def embed_finish(tokens, cls, pos=None, dropout: Dropout = NO_DROP):
+    _chk(tokens, torch.float32, "embed_finish tokens")
+    h = _h(tokens)
+    B, T, D = tokens.shape
+    p, seed, site = dropout
+    check(h.lib.vit_embed_finish(h.h, tokens.data_ptr(), cls.data_ptr(), _ptr(pos), B, T, D, p, seed, site,
+                                 _stream(tokens)), "vit_embed_finish")
+    return tokens
+
+
+def embed_finish_bwd(dtokens, dcls, dpos=None, dropout: Dropout = NO_DROP, dpatch=None):
+    _chk(dtokens, torch.float32, "embed_finish_bwd dtokens")
+    h = _h(dtokens)
+    B, T, D = dtokens.shape
+    dpatch = dpatch if dpatch is not None else torch.empty((B * (T - 1), D), dtype=torch.bfloat16, device=dtokens.device)
+    p, seed, site = dropout
+    check(h.lib.vit_embed_finish_bwd(h.h, dtokens.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), _ptr(dpos), B, T, D, p,
+                                     seed, site, 0, _stream(dtokens)), "vit_embed_finish_bwd")
+    return dpatch
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def dropout_bwd_cast(dx, dropout: Dropout = NO_DROP, out=None):
+    _chk(dx, torch.float32, "dropout_bwd_cast dx")
+    h = _h(dx)
+    cols = dx.shape[-1]
+    rows = dx.numel() // cols
+    out = out if out is not None else torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
+    p, seed, site = dropout
+    check(h.lib.vit_dropout_bwd_cast(h.h, dx.data_ptr(), out.data_ptr(), rows, cols, p, seed, site, _stream(dx)),
+          "vit_dropout_bwd_cast")
+    return out
+
+
+def colsum(a, out=None, accumulate: bool = False):
+    h = _h(a)
+    rows, cols = a.shape
+    out = out if out is not None else torch.empty(cols, dtype=torch.float32, device=a.device)
+    check(h.lib.vit_colsum(h.h, a.data_ptr(), _DT[a.dtype], a.stride(0), out.data_ptr(), rows, cols, int(accumulate),
+                           _stream(a)), "vit_colsum")
+    return out
+
+
+def cast_f32_bf16(src, out=None):
+    _chk(src, torch.float32, "cast_f32_bf16 src")
+    h = _h(src)
+    out = out if out is not None else torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    check(h.lib.vit_cast_f32_bf16(h.h, src.data_ptr(), out.data_ptr(), src.numel(), _stream(src)), "vit_cast_f32_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ head + loss
+def head_loss_fwd(last_hidden, W, b, labels, loss_kind: int):
+    _chk(last_hidden, torch.float32, "head_loss_fwd last_hidden")
+    h = _h(last_hidden)
+    B, T, D = last_hidden.shape
+    Cn = W.shape[0]
+    logits = torch.empty((B, Cn), dtype=torch.float32, device=last_hidden.device)
+    loss = torch.zeros((), dtype=torch.float32, device=last_hidden.device) if labels is not None else None
+    check(h.lib.vit_head_loss_fwd(h.h, last_hidden.data_ptr(), W.data_ptr(), b.data_ptr(), _ptr(labels),
+                                  logits.data_ptr(), _ptr(loss), B, T, D, Cn, loss_kind, _stream(last_hidden)),
+          "vit_head_loss_fwd")
+    return logits, loss
+
+
+def head_loss_bwd(last_hidden, W, logits, labels, dloss, loss_kind: int, dlast=None, dW=None, db=None):
+    h = _h(last_hidden)
+    B, T, D = last_hidden.shape
+    Cn = W.shape[0]
+    dlast = dlast if dlast is not None else torch.empty_like(last_hidden)
+    dW = dW if dW is not None else torch.empty_like(W)
+    db = db if db is not None else torch.empty(Cn, dtype=torch.float32, device=W.device)
+    check(h.lib.vit_head_loss_bwd(h.h, last_hidden.data_ptr(), W.data_ptr(), logits.data_ptr(), labels.data_ptr(),
+                                  dloss.data_ptr(), dlast.data_ptr(), dW.data_ptr(), db.data_ptr(), B, T, D, Cn,
+                                  loss_kind, 0, _stream(last_hidden)), "vit_head_loss_bwd")
+    return dlast, dW, db
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def grad_sqnorm(g, out=None):
+    _chk(g, torch.float32, "grad_sqnorm g")
+    h = _h(g)
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=g.device)
+    check(h.lib.vit_grad_sqnorm(h.h, g.data_ptr(), g.numel(), out.data_ptr(), _stream(g)), "vit_grad_sqnorm")
+    return out
+
+
+def adamw_step(p, g, m, v, p_bf16, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step=1, sqnorm=None,
+               max_norm=0.0, n: Optional[int] = None):
+    h = _h(p)
+    n = p.numel() if n is None else n
+    check(h.lib.vit_adamw_step(h.h, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), n, lr, beta1,
+                               beta2, eps, weight_decay, step, _ptr(sqnorm), max_norm, _stream(p)), "vit_adamw_step")
