@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ViT training hot path (BASELINE.json metric: images/sec of a ViT-B/16 224^2 bf16 train step).
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full optimisation step of the reference's `training_step` path on one synthetic batch that is already
+resident in HBM: forward (dropout on) -> backward -> [RCCL gradient all-reduce, overlapped] -> global-norm clip 0.5 ->
+AdamW.  Workload = SURVEY.md section 8 config C3: flux [256, 50176] f32 per GPU (a 224x224x1 image flattened),
+patch 256 (=16^2) -> 196 tokens + CLS, hidden 768, 12 heads, 12 layers, MLP 3072, 85.8 M parameters, regression head,
+MSE loss (what baseline.yaml's loss.name 'mae' resolves to), AdamW lr 1e-3 wd 0.  Weak scaling: 256 images per GPU.
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline     -- the dominant kernel (by summed time) of the step: algorithmic FLOPs per launch / mean launch duration,
+                  measured live with HIP events on the launch stream during the timed steps, against the dense bf16
+                  MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); `step_frac` is the whole-step model-FLOPs utilisation.
+  cpu_baseline -- the CPU oracle (oracle/refvit.py, plain fp32 torch: a "port") timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE = 2.5e15  # FLOP/s, MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+
+WORKLOADS = {
+    # name: (image_size, patch, hidden, layers, heads, per-GPU batch)
+    "vit_b16_224": (50176, 256, 768, 12, 12, 256),
+    "vit_l16_384": (147456, 256, 1024, 24, 16, 32),
+    "vit_tiny16_32": (1024, 256, 192, 12, 3, 64),
+    "baseline_yaml": (4096, 32, 32, 3, 2, 64),
+}
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def train_flop_per_image(L, P, D, layers, F):
+    """2*3*[N*P*D + layers*(3TD^2 + 2T^2 D + TD^2 + 2TDF) + D^2 + D]."""
+    N = L // P
+    T = N + 1
+    macs = N * P * D + layers * (3 * T * D * D + 2 * T * T * D + T * D * D + 2 * T * D * F) + D * D + D
+    return 6.0 * macs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
+    args = ap.parse_args()
+
+    import torch
+
+    from vit_amd import ddp as ddp_mod
+    from vit_amd import functional as vf
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    rank, local, world = ddp_mod.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    L, P, D, layers, heads, B = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    config = {
+        "model": dict(name="vit", task_type="reg", image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
+                      num_attention_heads=heads, stride_size=P, proj_fn="SW"),
+        "train": dict(batch_size=B, ep=1, precision="bf16-mixed"),
+        "loss": {"name": "mae"},
+        "opt": {"type": "AdamW", "lr": 1e-3},
+        "data": {"param": "log_g"},
+        "noise": {"noise_level": 0},
+    }
+    seed_everything(42)  # scripts/run.py:22,28
+    module = ViTLModule(config=config)
+    trainer = Trainer(config["train"], device=dev, verbose=False)
+    trainer._setup(module)
+    module.train()
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    flux = torch.randn((B, L), generator=g).to(dev)
+    error = (0.1 * torch.randn((B, L), generator=g).abs()).to(dev)
+    labels = torch.rand((B,), generator=g).to(dev)
+    batch = (flux, error, labels)
+
+    # ---- per-GEMM event brackets (the launches all go to torch's current stream, which the events are recorded on)
+    records = []
+    if not args.no_kernel_timing:
+        orig_gemm = vf.gemm
+
+        def timed_gemm(a, b, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_gemm(a, b, **kw)
+            e1.record()
+            if timing_on[0]:
+                records.append(((int(bool(kw.get("a_trans"))), int(bool(kw.get("b_trans")))), kw["M"], kw["N"], kw["K"], e0, e1))
+            return out
+
+        timing_on = [False]
+        vf.gemm = timed_gemm
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        log(f"model on {dev}, {sum(p.numel() for p in module.parameters())} parameters; warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        trainer.training_step(module, batch, i)
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"timing {args.steps} steps")
+    if not args.no_kernel_timing:
+        timing_on[0] = True
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.training_step(module, batch, i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss.detach())
+    if rank == 0:
+        log(f"{args.steps} steps in {dt:.3f} s -> {world * B * args.steps / dt:.1f} images/s, loss {final_loss:.5f}")
+
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    F = 4 * D
+    flop_img = train_flop_per_image(L, P, D, layers, F)
+
+    roofline = None
+    kernels = {}
+    if not args.no_kernel_timing and rank == 0:
+        agg = {}
+        for var, M, N, K, e0, e1 in records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(var, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += 2.0 * M * N * K
+        names = {(0, 0): "gemm_bf16_kernel<0,0> (Y = X W^T: forward)", (0, 1): "gemm_bf16_kernel<0,1> (dX = dY W)",
+                 (1, 1): "gemm_bf16_kernel<1,1> (dW = dY^T X, + split-K reduce)", (1, 0): "gemm_bf16_kernel<1,0>"}
+        for var, (n, ms, fl) in agg.items():
+            kernels[names[var]] = dict(launches=n, total_ms=round(ms, 3), mean_us=round(ms / n * 1e3, 2),
+                                       tflops=round(fl / (ms * 1e-3) / 1e12, 1))
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        var, (n, ms, fl) = dom
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": names[var], "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12,
+            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+            "flop_per_launch": fl / n, "mean_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
+            "share_of_step_time": round(ms / (dt * 1e3), 3),
+            "step_tflops": round(value / world * flop_img / 1e12, 2),
+            "step_frac": round(value / world * flop_img / PEAK_BF16_DENSE, 4),
+        }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args.workload, L, P, D, layers, heads)
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec ViT-B/16 224^2 bf16 train step" if args.workload == "vit_b16_224" else f"images/sec {args.workload} bf16 train step",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
+                                   f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
+                       "final_loss": final_loss},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def run_cpu_baseline(workload, L, P, D, layers, heads):
+    """The CPU oracle (plain fp32 torch restatement of the reference path; 'port') on this host's cores: same step
+    (fwd, dropout on, bwd, clip 0.5, AdamW), bounded sample."""
+    import torch
+
+    from oracle import refvit
+
+    # the GPU box gives this job a 16-core share of a much larger host: os.cpu_count() would oversubscribe it
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("VIT_BENCH_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} threads, building oracle state")
+    rc = refvit.RefConfig(image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
+                          num_attention_heads=heads, stride_size=P, loss_name="mae")
+    Bc = 8 if D >= 512 else 64
+    sd = refvit.make_state_dict(rc, 7)
+    flux, _, labels = refvit.make_inputs(rc, Bc, 8)
+    tr = refvit.RefTrainer(rc, sd, training=True)
+    t0 = time.perf_counter()
+    tr.step(flux, labels)  # warm-up
+    log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f} s")
+    n = 2
+    t0 = time.perf_counter()
+    for i in range(n):
+        tr.step(flux, labels)
+        log(f"cpu baseline: step {i + 1}/{n} at {time.perf_counter() - t0:.1f} s")
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{workload}: batch {Bc}, 1 warm-up + {n} timed steps, fp32, dropout on, oracle/refvit.py RefTrainer "
+                      f"({dt / n:.2f} s/step)"}
+
+
+if __name__ == "__main__":
+    main()

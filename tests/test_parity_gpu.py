@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through MyViT -> engine -> C ABI) with the golden vectors generated from the reference's
+own modules (tests/golden/*.npz, oracle/make_golden.py) and with the CPU oracle on the same seeded inputs.
+
+Tolerances (stated per north_star):
+  * the MFMA contractions consume bf16 operands (fp32 accumulate, fp32 residual stream / LN / softmax statistics), i.e.
+    the arithmetic of the reference under precision='bf16-mixed'.  The fixtures hold the reference's fp32 outputs AND
+    its own bf16-autocast outputs; the reference's bf16 run differs from its fp32 run by 4e-3..7e-3 (relative L2), so a
+    1e-3 match to the fp32 outputs is not reachable by ANY bf16 pipeline.  The gate is therefore:
+        err(ours, ref_fp32) <= 1.5 * err(ref_bf16_autocast, ref_fp32) + 1e-3        (no worse than the reference's own
+    bf16 mode), and in absolute terms relative-L2 <= 1.5e-2 on every hidden state.
+  * gradients: relative L2 <= 4e-2 and cosine >= 0.999 per tensor against the reference's fp32 autograd.
+  * fused AdamW vs torch.optim.AdamW on the same gradients: <= 2e-6 relative after one step (kernel test: 1e-6 over 3).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def setup(tag, dev):
+    from oracle import refvit
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    rcs = {
+        "c1": refvit.named_config("C1"),
+        "c2": refvit.named_config("C2"),
+        "r1": refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2,
+                               num_attention_heads=4, stride_size=48, num_labels=3, loss_name="l1"),
+        "k1": refvit.RefConfig(image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=2,
+                               num_attention_heads=2, stride_size=32, task_type="cls", num_labels=5,
+                               pos_encoding_type="learned", loss_name="ce"),
+    }
+    rc = rcs[tag]
+    g = np.load(os.path.join(GOLD, f"{tag}.npz"))
+    sd = refvit.make_state_dict(rc, int(g["wseed"]))
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["weight_checksum"])) < 1e-6
+    cfg = ViTConfig(task_type=rc.task_type, image_size=rc.image_size, patch_size=rc.patch_size,
+                    hidden_size=rc.hidden_size, num_hidden_layers=rc.num_hidden_layers,
+                    num_attention_heads=rc.num_attention_heads, proj_fn=rc.proj_fn, stride_size=rc.stride_size,
+                    num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type)
+    model = MyViT(cfg, loss_name=rc.loss_name)
+    missing = model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    x = torch.from_numpy(g["flux"]).to(dev)
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    return rc, g, sd, model, x, labels
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2", "r1", "k1"])
+def test_eval_forward_matches_reference(dev, tag):
+    rc, g, sd, model, x, labels = setup(tag, dev)
+    model.eval()
+    out = model(x, labels=labels, output_hidden_states=True, output_attentions=True)
+    T = lambda k: torch.from_numpy(g[k])
+    ref_err = rel(T("bf16_last_hidden_state"), T("last_hidden_state"))
+    hs = torch.stack([h.cpu() for h in out.hidden_states])
+    assert hs.shape == T("hidden_states").shape
+    # tokens (patch embedding) and every hidden state
+    N = rc.num_patches
+    emb = out.hidden_states[0].cpu()
+    if rc.pos_encoding_type == "learned":
+        emb = emb - sd["vit.embeddings.position_embeddings"]
+    assert rel(emb[:, 1:], T("tokens")) < 6e-3
+    assert rel(emb[:, 0], sd["vit.embeddings.cls_token"].view(1, -1).expand(emb.shape[0], -1)) < 1e-6
+    errs = [rel(hs[i], T("hidden_states")[i]) for i in range(hs.shape[0])]
+    assert max(errs) < 1.5e-2, errs
+    assert rel(out.attentions[0], T("attn0")) < 1.5e-2
+    assert rel(out.attentions[-1], T("attn_last")) < 2e-2
+    # logits / loss: no worse than the reference's own bf16 mode
+    e_logits = rel(out.logits, T("logits"))
+    e_ref = rel(T("bf16_logits"), T("logits"))
+    assert e_logits <= 1.5 * max(e_ref, ref_err) + 1e-3, (e_logits, e_ref)
+    assert abs(float(out.loss) - float(g["loss"])) <= 3e-2 * abs(float(g["loss"])) + 1e-4
+    print(f"[{tag}] hidden-state rel errs max {max(errs):.2e}; logits {e_logits:.2e} (reference bf16 mode: {e_ref:.2e})")
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2", "r1", "k1"])
+def test_gradients_match_reference(dev, tag):
+    rc, g, sd, model, x, labels = setup(tag, dev)
+    model.eval()  # dropout off: masks are implementation-defined, so gradient parity is asserted at p = 0
+    loss = model(x, labels=labels).loss
+    loss.backward()
+    names = [str(n) for n in g["param_names"]]
+    gn = g["grad_norms"]
+    worst = 0.0
+    for name, p in model.named_parameters():
+        i = names.index(name)
+        if f"grad/{name}" not in g.files:
+            assert p.grad is None, name  # pooler
+            continue
+        ref = torch.from_numpy(g[f"grad/{name}"])
+        mine = p.grad.detach().cpu().flatten()
+        if f"gidx/{name}" in g.files:
+            mine = mine[torch.from_numpy(g[f"gidx/{name}"])]
+            ref = ref.flatten()
+        else:
+            ref = ref.flatten()
+        if gn[i] < 1e-6:  # key.bias: analytically zero
+            assert float(p.grad.norm()) < 1e-3 * (1 + float(max(gn))), name
+            continue
+        e = rel(mine, ref)
+        cos = float(torch.dot(mine.double(), ref.double()) / (mine.double().norm() * ref.double().norm() + 1e-30))
+        # per-tensor norms too (covers the un-sampled entries of the big tensors)
+        nrm = float(p.grad.double().norm())
+        assert abs(nrm - gn[i]) <= 4e-2 * gn[i] + 1e-7, (name, nrm, gn[i])
+        assert e < 4e-2 and cos > 0.999, (name, e, cos)
+        worst = max(worst, e)
+    print(f"[{tag}] worst gradient rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("tag", ["c1", "k1"])
+def test_training_steps_track_reference(dev, tag):
+    """3 steps of: fwd -> bwd -> clip_grad_norm_(0.5) -> AdamW(lr 1e-3, wd 0), dropout off; fused optimizer path."""
+    from vit_amd.optimizer import OptModule
+
+    rc, g, sd, model, x, labels = setup(tag, dev)
+    model.eval()
+    opt = OptModule.from_config({"type": "AdamW", "lr": 1e-3})(model)
+    opt.set_grad_clip(0.5)
+    losses, norms = [], []
+    for s in range(3):
+        opt.zero_grad()
+        loss = model(x, labels=labels).loss
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        norms.append(float(opt.last_grad_norm.sqrt()))
+    ref_l, ref_n = g["step_losses"], g["step_grad_norms"]
+    for a, b in zip(losses, ref_l):
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-4, (losses, ref_l)
+    # step 1 sees identical weights; later steps compound Adam's sign-like first updates (+-lr per element, so bf16
+    # noise on near-zero gradients flips whole steps) -- in the reference's own bf16 mode too
+    for s_, (a, b) in enumerate(zip(norms, ref_n)):
+        assert abs(a - b) <= (4e-2 if s_ == 0 else 1e-1) * abs(b), (norms, ref_n)
+    # parameter movement after 3 steps: compare the update direction on tensors with a healthy gradient
+    moved = 0
+    for name, p in model.named_parameters():
+        k = f"after3/{name}"
+        if k not in g.files or f"gidx/{name}" in g.files:
+            continue
+        ref_delta = torch.from_numpy(g[k]).flatten() - sd[name].flatten()
+        my_delta = p.detach().cpu().flatten() - sd[name].flatten()
+        if float(ref_delta.norm()) < 1e-6:
+            continue
+        cos = float(torch.dot(my_delta.double(), ref_delta.double()) / (my_delta.double().norm() * ref_delta.double().norm()))
+        if "key.bias" in name:
+            continue  # zero gradient: Adam turns rounding noise into +-lr steps, in the reference too
+        assert cos > 0.9, (name, cos)  # Adam's first steps are sign-like: bf16 noise flips a few +-lr element steps
+        moved += 1
+    assert moved > 10
+
+
+def test_fused_adamw_equals_torch_adamw(dev):
+    """Same model, same gradients: FusedAdamW (+ fused clip) vs clip_grad_norm_ + torch.optim.AdamW on the .grad views."""
+    from vit_amd.optimizer import FusedAdamW
+
+    rc, g, sd, model, x, labels = setup("c1", dev)
+    rc2, g2, sd2, model2, _, _ = setup("c1", dev)
+    model.eval()
+    model2.eval()
+    fused = FusedAdamW(model, lr=1e-3, weight_decay=0.01)
+    fused.set_grad_clip(0.5)
+    ref = torch.optim.AdamW(model2.parameters(), lr=1e-3, weight_decay=0.01)
+    for s in range(3):
+        fused.zero_grad()
+        ref.zero_grad(set_to_none=True)
+        model(x, labels=labels).loss.backward()
+        model2(x, labels=labels).loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for p in model2.parameters() if p.grad is not None], 0.5)
+        fused.step()
+        ref.step()
+        for (n1, p1), (n2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+            if "key.bias" in n1:
+                continue  # analytically zero gradient: Adam normalises pure rounding noise into +-lr steps
+            # step 0 is exact to rounding; afterwards a 1-ulp difference in an updated f32 weight (torch divides by
+            # sqrt(bc2), the kernel multiplies by its reciprocal) can flip that weight's bf16 rounding, and Adam's
+            # normalisation amplifies the resulting gradient noise.  Exact equivalence on identical gradients is
+            # asserted at kernel level (test_kernels_gpu.py::test_sqnorm_adamw).
+            assert rel(p1.detach(), p2.detach()) < (2e-6 if s == 0 else 2e-4), (s, n1)
+
+
+def test_state_dict_names_and_roundtrip(dev):
+    rc, g, sd, model, x, labels = setup("k1", dev)
+    got = model.state_dict()
+    assert list(got.keys()) == list(sd.keys()) or sorted(got.keys()) == sorted(sd.keys())
+    for k in sd:
+        assert torch.equal(got[k].cpu(), sd[k]), k
+    # hot reload of new weights is picked up by the bf16 shadow
+    model.eval()
+    l0 = float(model(x, labels=labels).loss)
+    sd2 = {k: v * 0.5 for k, v in sd.items()}
+    model.load_state_dict(sd2)
+    l1 = float(model(x, labels=labels).loss)
+    assert l0 != l1
+    model.load_state_dict(sd)
+    assert abs(float(model(x, labels=labels).loss) - l0) < 1e-6
+
+
+def test_training_mode_dropout_statistics(dev):
+    """Dropout on (train mode): loss differs between steps/seeds, is finite, and its mean over seeds stays close to the
+    eval loss scale; backward runs and yields finite gradients."""
+    rc, g, sd, model, x, labels = setup("c1", dev)
+    model.train()
+    vals = []
+    for _ in range(8):
+        for p in model.parameters():
+            p.grad = None
+        loss = model(x, labels=labels).loss
+        loss.backward()
+        vals.append(float(loss))
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+        assert torch.isfinite(gn)
+    assert len(set(round(v, 7) for v in vals)) > 1
+    assert all(np.isfinite(vals))
+
+
+def test_cpu_tensor_fails_loudly():
+    from vit_amd._cabi import VitError
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    cfg = ViTConfig(task_type="reg", image_size=256, patch_size=32, hidden_size=32, num_hidden_layers=1,
+                    num_attention_heads=2, stride_size=32)
+    m = MyViT(cfg, loss_name="mae")
+    with pytest.raises(VitError):
+        m(torch.zeros(2, 256), labels=torch.zeros(2))

@@ -1,0 +1,102 @@
+"""Data-parallel gradient exchange for the ViT step: the one collective the path has.
+
+The reference gets this implicitly from Lightning's `strategy='ddp'` (src/hardware_utils.py:86-95): torch-DDP
+all-reduces bucketed gradients during backward.  Here the gradients already live in ONE flat f32 buffer laid out in the
+order backward completes them (tail, layer L-1 .. 0, embeddings), so each bucket is a contiguous slice: as soon as the
+engine reports a slice complete, an asynchronous RCCL all-reduce (mean) is enqueued on it while the next layer's
+backward kernels keep the compute stream busy; `finish()` joins before the norm-clip + AdamW kernel.  One process per
+GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI); "gloo" is supported for CPU rehearsals/tests.
+
+The pooler parameters never receive a gradient (their output is unused, specvit.py:78), so they are simply outside every
+bucket -- torch-DDP with find_unused_parameters=False would raise on them.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["GradAllReducer", "broadcast_parameters", "init_distributed", "shard_indices"]
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun contract) and create the default process group."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def broadcast_parameters(flat: torch.Tensor, src: int = 0, group=None):
+    """DDP start-up semantics: every replica begins from rank 0's parameters."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+
+
+def shard_indices(n: int, rank: int, world: int, epoch: int, shuffle: bool, seed: int = 0) -> torch.Tensor:
+    """DistributedSampler semantics (pad by wrapping so every rank gets ceil(n/world) samples)."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g)
+    else:
+        idx = torch.arange(n)
+    per = -(-n // world)
+    total = per * world
+    if total > n:
+        idx = torch.cat([idx, idx[: total - n]])
+    return idx[rank:total:world]
+
+
+class GradAllReducer:
+    """Mean all-reduce of the slices [lo, hi) of one flat gradient buffer, launched as they become ready."""
+
+    def __init__(self, grads_getter, buckets: List[Tuple[int, int]], group=None, max_bucket_elems: int = 64 << 20):
+        self._get = grads_getter
+        self.buckets = buckets
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.max_bucket_elems = max_bucket_elems
+        self._pending = []
+        self._seen = 0
+        self.bytes_reduced = 0
+
+    def bucket_ready(self, lo: int, hi: int):
+        """Engine callback (called on the host right after the kernels that complete grads[lo:hi] were enqueued)."""
+        if self.world <= 1 or hi <= lo:
+            return
+        g = self._get()
+        # an all-reduce bigger than max_bucket_elems is split so that the first pieces are on the wire early
+        for a in range(lo, hi, self.max_bucket_elems):
+            b = min(hi, a + self.max_bucket_elems)
+            t = g[a:b]
+            backend = dist.get_backend(self.group)
+            if backend == "nccl":
+                w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                self._pending.append((w, None))
+            else:
+                w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._pending.append((w, t))
+            self.bytes_reduced += t.numel() * t.element_size()
+        self._seen += 1
+
+    def finish(self):
+        """Join every outstanding all-reduce (the compute stream waits on RCCL's stream; no host sync with nccl)."""
+        for w, t in self._pending:
+            w.wait()
+            if t is not None:
+                t.div_(self.world)
+        self._pending = []
+        self._seen = 0

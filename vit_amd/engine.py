@@ -1,0 +1,389 @@
+"""Host-side engine of the ViT step: owns the flat parameter / gradient buffers and the activation arena in HBM and
+sequences the HIP kernels of libvit_amd.so (through vit_amd.functional -> ctypes -> C ABI) for forward and backward.
+
+Data layout in HBM (one MI355X, 288 GB: nothing is recomputed or re-materialised to save memory)
+  params   f32 [n_total]   flat; every tensor of the reference's state_dict (transformers-4.56 names) is a view.
+                           query/key/value weights (and biases) of a layer are adjacent, so the fused QKV projection
+                           reads them as one [3D, D] matrix.  Pooler last (never receives a gradient: specvit.py:78).
+  shadow   bf16 [n_total]  same offsets; what the MFMA GEMMs read.  Refreshed by the fused AdamW kernel, or by one cast
+                           pass whenever the f32 buffer was modified behind our back (load_state_dict, a torch optimizer).
+  grads    f32 [n_total]   same offsets; every kernel that produces a parameter gradient writes its slice exactly once.
+  arena    per layer: x_in f32 [M,D] (residual stream), h1/h2 bf16 [M,D] (LN outputs), qkv bf16 [M,3D], ctx bf16 [M,D],
+           lse f32 [B*H,T], x1 f32 [M,D], u/g bf16 [M,4D] (pre/post GELU), LN statistics.  M = B*T token rows.
+Dropout masks are regenerated from (seed, site) in backward; no mask is stored.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import functional as vf
+from ._cabi import ACT_GELU, LOSS_CE, LOSS_L1, LOSS_MSE, VitError
+from .config import ViTConfig
+
+ALIGN = 8  # elements; keeps every view 32-byte (f32) / 16-byte (bf16) aligned
+
+
+def resolved_loss(task_type: str, loss_name: str) -> Tuple[str, int]:
+    """specvit.py:45-55: cls -> CrossEntropy ('ce'); reg -> L1 iff 'l1' in loss_name.lower() else MSE."""
+    if task_type == "cls":
+        return "ce", LOSS_CE
+    if task_type == "reg":
+        ln = loss_name or "l2"
+        return ln, (LOSS_L1 if "l1" in ln.lower() else LOSS_MSE)
+    raise ValueError(f"Unsupported task_type '{task_type}'")
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside the flat buffers; `state_order` is the reference's state_dict order."""
+
+    def __init__(self, cfg: ViTConfig):
+        D, P, Fd, T = cfg.hidden_size, cfg.patch_size, cfg.intermediate_size, cfg.seq_len
+        self.entries: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.layer_ranges: List[Tuple[int, int]] = []
+        off = 0
+
+        def add(name, shape):
+            nonlocal off
+            n = 1
+            for s in shape:
+                n *= s
+            self.entries[name] = (off, tuple(shape))
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+
+        e = "vit.embeddings."
+        self.embed_start = off
+        add(e + "cls_token", (1, 1, D))
+        if cfg.pos_encoding_type == "learned":
+            add(e + "position_embeddings", (1, T, D))
+        add(e + "patch_embeddings.projection.weight", (D, P) if cfg.proj_fn == "SW" else (D, 1, P))
+        add(e + "patch_embeddings.projection.bias", (D,))
+        self.embed_end = off
+        for i in range(cfg.num_hidden_layers):
+            p = f"vit.encoder.layer.{i}."
+            start = off
+            for n in ("query", "key", "value"):
+                add(p + f"attention.attention.{n}.weight", (D, D))
+            for n in ("query", "key", "value"):
+                add(p + f"attention.attention.{n}.bias", (D,))
+            add(p + "attention.output.dense.weight", (D, D))
+            add(p + "attention.output.dense.bias", (D,))
+            add(p + "intermediate.dense.weight", (Fd, D))
+            add(p + "intermediate.dense.bias", (Fd,))
+            add(p + "output.dense.weight", (D, Fd))
+            add(p + "output.dense.bias", (D,))
+            add(p + "layernorm_before.weight", (D,))
+            add(p + "layernorm_before.bias", (D,))
+            add(p + "layernorm_after.weight", (D,))
+            add(p + "layernorm_after.bias", (D,))
+            self.layer_ranges.append((start, off))
+        self.tail_start = off
+        add("vit.layernorm.weight", (D,))
+        add("vit.layernorm.bias", (D,))
+        head = "classifier" if cfg.task_type == "cls" else "regressor"
+        self.head = head
+        add(head + ".weight", (cfg.num_labels, D))
+        add(head + ".bias", (cfg.num_labels,))
+        self.n_trainable = off
+        add("vit.pooler.dense.weight", (D, D))
+        add("vit.pooler.dense.bias", (D,))
+        self.n_total = off
+        # the order MyViT's state_dict has in the reference (HF module registration order)
+        order = [e + "cls_token"]
+        if cfg.pos_encoding_type == "learned":
+            order.append(e + "position_embeddings")
+        order += [e + "patch_embeddings.projection.weight", e + "patch_embeddings.projection.bias"]
+        for i in range(cfg.num_hidden_layers):
+            p = f"vit.encoder.layer.{i}."
+            for n in ("query", "key", "value"):
+                order += [p + f"attention.attention.{n}.weight", p + f"attention.attention.{n}.bias"]
+            for n in ("attention.output.dense", "intermediate.dense", "output.dense", "layernorm_before", "layernorm_after"):
+                order += [p + n + ".weight", p + n + ".bias"]
+        order += ["vit.layernorm.weight", "vit.layernorm.bias", "vit.pooler.dense.weight", "vit.pooler.dense.bias",
+                  head + ".weight", head + ".bias"]
+        assert sorted(order) == sorted(self.entries)
+        self.state_order = order
+
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        off, shape = self.entries[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[off:off + n].view(shape)
+
+    def numel(self, name: str) -> int:
+        n = 1
+        for s in self.entries[name][1]:
+            n *= s
+        return n
+
+    def buckets(self) -> List[Tuple[int, int]]:
+        """Gradient buckets in the order backward completes them: tail (final LN + head), layers L-1..0, embeddings."""
+        return [(self.tail_start, self.n_trainable)] + list(reversed(self.layer_ranges)) + \
+               [(self.embed_start, self.embed_end)]
+
+
+class ViTEngine:
+    def __init__(self, cfg: ViTConfig, loss_name: str = ""):
+        if cfg.pos_encoding_type == "rope":
+            raise NotImplementedError("pos_encoding_type='rope' is a SURVEY section 8(f) 'next' row")
+        if cfg.pos_encoding_type not in (None, "none", "learned"):
+            raise ValueError(f"Unsupported pos_encoding_type '{cfg.pos_encoding_type}'. "
+                             f"Choose from: 'rope', 'learned', 'none', or None")  # embedding.py:74
+        if cfg.proj_fn not in ("SW", "C1D", "CNN"):
+            raise ValueError(f"Unsupported proj_fn '{cfg.proj_fn}'")  # embedding.py:44
+        self.cfg = cfg
+        self.loss_name, self.loss_kind = resolved_loss(cfg.task_type, loss_name)
+        self.layout = ParamLayout(cfg)
+        self.flat = torch.zeros(self.layout.n_total, dtype=torch.float32)
+        self.shadow: Optional[torch.Tensor] = None
+        self.grads: Optional[torch.Tensor] = None
+        self._shadow_version = -1
+        self._arena_key = None
+        self.act: Dict[str, object] = {}
+        self.tmp: Dict[str, torch.Tensor] = {}
+        self.base_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        self.step_counter = 0
+        self._last = None
+        self.grad_ready_cb: Optional[Callable[[int, int], None]] = None
+        # Parameters are views of `flat` with their OWN version counters (nn.Parameter / .data re-pointing do not share
+        # the base's), so "were the f32 weights modified since the bf16 shadow was made?" is answered by a signature
+        # over the parameters' versions, supplied by the owning module.
+        self.version_fn: Callable[[], int] = lambda: self.flat._version
+
+    # ------------------------------------------------------------------ parameters
+    @property
+    def device(self):
+        return self.flat.device
+
+    def rebind(self, new_flat: torch.Tensor):
+        if new_flat.dtype != torch.float32:
+            raise VitError("vit_amd keeps master parameters in fp32 (precision '32' / 'bf16-mixed' semantics); "
+                           "casting the module to another dtype is not supported")
+        self.flat = new_flat.contiguous()
+        self.shadow = None
+        self.grads = None
+        self._shadow_version = -1
+        self._arena_key = None
+        self.act, self.tmp = {}, {}
+
+    def p(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.flat, name)
+
+    def _ensure_device_state(self):
+        if not self.flat.is_cuda:
+            raise VitError("vit_amd runs on an MI355X only: move the model to the GPU first (model.to('cuda')); "
+                           "there is no CPU fallback path")
+        if self.shadow is None:
+            self.shadow = torch.empty(self.layout.n_total, dtype=torch.bfloat16, device=self.flat.device)
+            self.grads = torch.zeros(self.layout.n_total, dtype=torch.float32, device=self.flat.device)
+            self._shadow_version = -1
+        ver = self.version_fn()
+        if self._shadow_version != ver:
+            vf.cast_f32_bf16(self.flat, self.shadow)
+            self._shadow_version = ver
+
+    def mark_shadow_fresh(self):
+        self._shadow_version = self.version_fn()
+
+    def w16(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.shadow, name)
+
+    def g(self, name: str) -> torch.Tensor:
+        return self.layout.view(self.grads, name)
+
+    def _qkv16(self, i: int):
+        off, _ = self.layout.entries[f"vit.encoder.layer.{i}.attention.attention.query.weight"]
+        D = self.cfg.hidden_size
+        return self.shadow[off:off + 3 * D * D].view(3 * D, D)
+
+    def _qkv_bias(self, i: int, buf: torch.Tensor):
+        off, _ = self.layout.entries[f"vit.encoder.layer.{i}.attention.attention.query.bias"]
+        D = self.cfg.hidden_size
+        return buf[off:off + 3 * D]
+
+    def _qkv_wgrad(self, i: int):
+        off, _ = self.layout.entries[f"vit.encoder.layer.{i}.attention.attention.query.weight"]
+        D = self.cfg.hidden_size
+        return self.grads[off:off + 3 * D * D].view(3 * D, D)
+
+    # ------------------------------------------------------------------ arena
+    def _ensure_arena(self, B: int, train: bool):
+        key = (B, train)
+        if self._arena_key == key:
+            return
+        c = self.cfg
+        dev = self.flat.device
+        T, D, Fd, H, L, N, P = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
+            c.num_hidden_layers, c.num_patches, c.patch_size
+        M = B * T
+        nl = L if train else 1
+        f32, b16 = torch.float32, torch.bfloat16
+
+        def E(shape, dt):
+            return torch.empty(shape, dtype=dt, device=dev)
+
+        self.act = dict(
+            patches=E((B * N, P), b16),
+            x=[E((B, T, D), f32) for _ in range(L + 1)],
+            h1=[E((M, D), b16) for _ in range(nl)], qkv=[E((M, 3 * D), b16) for _ in range(nl)],
+            ctx=[E((M, D), b16) for _ in range(nl)], lse=[E((B * H, T), f32) for _ in range(nl)],
+            x1=[E((M, D), f32) for _ in range(nl)], h2=[E((M, D), b16) for _ in range(nl)],
+            u=[E((M, Fd), b16) for _ in range(nl)], g=[E((M, Fd), b16) for _ in range(nl)],
+            mean1=[E((M,), f32) for _ in range(nl)], rstd1=[E((M,), f32) for _ in range(nl)],
+            mean2=[E((M,), f32) for _ in range(nl)], rstd2=[E((M,), f32) for _ in range(nl)],
+            last=E((B, T, D), f32), meanF=E((M,), f32), rstdF=E((M,), f32),
+        )
+        self.tmp = {}
+        if train:
+            self.tmp = dict(
+                dxa=E((M, D), f32), dxb=E((M, D), f32), dy=E((M, D), b16), dU=E((M, Fd), b16), dh=E((M, D), b16),
+                dqkv=E((M, 3 * D), b16), dctx=E((M, D), b16), delta=E((B * H, T), f32), dpatch=E((B * N, D), b16),
+                dlast=E((B, T, D), f32),
+            )
+        self._arena_key = key
+
+    # ------------------------------------------------------------------ forward
+    def _site(self, layer: int, which: int) -> int:
+        return 1 + 4 * layer + which
+
+    def forward(self, x: torch.Tensor, labels: Optional[torch.Tensor], training: bool, need_grad: bool,
+                output_hidden_states: bool = False, output_attentions: bool = False):
+        c = self.cfg
+        self._ensure_device_state()
+        if x.dim() != 2 or x.shape[1] != c.image_size:
+            raise ValueError(f"pixel_values must be [batch, {c.image_size}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise VitError("pixel_values must live on the GPU")
+        x = x.contiguous().to(torch.float32)
+        B = x.shape[0]
+        T, D, Fd, H, L, N, P, S = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
+            c.num_hidden_layers, c.num_patches, c.patch_size, c.stride
+        dh, M = c.head_dim, B * T
+        self._ensure_arena(B, need_grad)
+        a = self.act
+        ph = c.hidden_dropout_prob if training else 0.0
+        pa = c.attention_probs_dropout_prob if training else 0.0
+        if training:
+            self.step_counter += 1
+        seed = (self.base_seed + 0x9E3779B97F4A7C15 * self.step_counter) & 0xFFFFFFFFFFFFFFFF
+        scale = dh ** -0.5
+        eps = c.layer_norm_eps
+        e = "vit.embeddings."
+
+        # --- embeddings: unfold -> projection (+bias) into token rows 1..N -> CLS / pos-emb / dropout
+        vf.unfold_cast(x, P, S, N, out=a["patches"])
+        wp = self.w16(e + "patch_embeddings.projection.weight").view(D, P)
+        x0 = a["x"][0]
+        vf.gemm(a["patches"], wp, M=B * N, N=D, K=P, out=x0.view(M, D), bias=self.p(e + "patch_embeddings.projection.bias"),
+                row_map=(N, T, 1))
+        pos = self.p(e + "position_embeddings").view(T, D) if c.pos_encoding_type == "learned" else None
+        vf.embed_finish(x0, self.p(e + "cls_token").view(D), pos, dropout=(ph, seed, 0))
+
+        atts = [] if output_attentions else None
+        for i in range(L):
+            j = i if need_grad else 0
+            pre = f"vit.encoder.layer.{i}."
+            xin = a["x"][i].view(M, D)
+            self._ln(xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
+            vf.gemm(a["h1"][j], self._qkv16(i), M=M, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
+            vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
+                             lse=a["lse"][j])
+            if output_attentions:
+                atts.append(vf.attention_probs(a["qkv"][j], B, H, T, dh, scale))
+            vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, out=a["x1"][j],
+                    bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)),
+                    residual=xin)
+            self._ln(a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
+            vf.gemm(a["h2"][j], self.w16(pre + "intermediate.dense.weight"), M=M, N=Fd, K=D, out=a["g"][j],
+                    bias=self.p(pre + "intermediate.dense.bias"), act=ACT_GELU, aux_out=a["u"][j] if need_grad else None)
+            vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=M, N=D, K=Fd, out=a["x"][i + 1].view(M, D),
+                    bias=self.p(pre + "output.dense.bias"), dropout=(ph, seed, self._site(i, 2)), residual=a["x1"][j])
+        self._ln(a["x"][L].view(M, D), "vit.layernorm", a["last"].view(M, D), a["meanF"], a["rstdF"])
+        hn = self.layout.head
+        if labels is not None:
+            labels = labels.to(self.flat.device)
+            labels = labels.contiguous().to(torch.int64 if self.loss_kind == LOSS_CE else torch.float32)
+            n_expected = B if self.loss_kind == LOSS_CE else B * c.num_labels
+            if labels.numel() != n_expected:
+                raise ValueError(f"labels has {labels.numel()} elements, expected {n_expected}")
+        logits, loss = vf.head_loss_fwd(a["last"], self.p(hn + ".weight"), self.p(hn + ".bias"), labels, self.loss_kind)
+        self._last = dict(B=B, seed=seed, ph=ph, pa=pa, labels=labels, logits=logits)
+        hs = [t.clone() for t in a["x"]] if output_hidden_states else None
+        return loss, logits, hs, atts
+
+    def _ln(self, x, name, out, mean, rstd):
+        vf.layernorm_fwd(x, self.p(name + ".weight"), self.p(name + ".bias"), self.cfg.layer_norm_eps, out=out,
+                         mean=mean, rstd=rstd)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dloss: torch.Tensor):
+        """Fill self.grads (every trainable slice exactly once) for the last forward; calls grad_ready_cb(lo, hi) as
+        each bucket of the flat gradient buffer is complete (used to overlap the RCCL all-reduce)."""
+        st = self._last
+        if st is None or st["labels"] is None:
+            raise VitError("backward without a preceding forward(labels=...)")
+        c = self.cfg
+        a, t = self.act, self.tmp
+        B, seed, ph, pa = st["B"], st["seed"], st["ph"], st["pa"]
+        T, D, Fd, H, L, N, P = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
+            c.num_hidden_layers, c.num_patches, c.patch_size
+        dh, M = c.head_dim, B * T
+        scale = dh ** -0.5
+        cb = self.grad_ready_cb
+        hn = self.layout.head
+        dloss = dloss.reshape(1).to(torch.float32).contiguous()
+
+        vf.head_loss_bwd(a["last"], self.p(hn + ".weight"), st["logits"], st["labels"], dloss, self.loss_kind,
+                         dlast=t["dlast"], dW=self.g(hn + ".weight"), db=self.g(hn + ".bias"))
+        dx, dx_other = t["dxa"], t["dxb"]
+        vf.layernorm_bwd(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
+                         a["rstdF"], dx=dx, dgamma=self.g("vit.layernorm.weight"), dbeta=self.g("vit.layernorm.bias"))
+        if cb:
+            cb(self.layout.tail_start, self.layout.n_trainable)
+        for i in reversed(range(L)):
+            pre = f"vit.encoder.layer.{i}."
+            # x2 = dropout(g W2^T + b2) + x1
+            vf.dropout_bwd_cast(dx, (ph, seed, self._site(i, 2)), out=t["dy"])
+            vf.colsum(t["dy"], out=self.g(pre + "output.dense.bias"))
+            vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=M, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
+                    split_k=-1)
+            vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=M, N=Fd, K=D, b_trans=True, out=t["dU"],
+                    act=vf.ACT_DGELU, aux_in=a["u"][i])
+            vf.colsum(t["dU"], out=self.g(pre + "intermediate.dense.bias"))
+            vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=M, a_trans=True, b_trans=True,
+                    out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
+            vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=M, N=D, K=Fd, b_trans=True, out=t["dh"])
+            vf.layernorm_bwd(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i], a["rstd2"][i],
+                             dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_after.weight"),
+                             dbeta=self.g(pre + "layernorm_after.bias"))
+            dx, dx_other = dx_other, dx
+            # x1 = dropout(ctx Wo^T + bo) + x
+            vf.dropout_bwd_cast(dx, (ph, seed, self._site(i, 1)), out=t["dy"])
+            vf.colsum(t["dy"], out=self.g(pre + "attention.output.dense.bias"))
+            vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=M, a_trans=True, b_trans=True,
+                    out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
+            vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, b_trans=True, out=t["dctx"])
+            vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
+                             dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"])
+            vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
+            vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=M, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
+                    split_k=-1)
+            vf.gemm(t["dqkv"], self._qkv16(i), M=M, N=D, K=3 * D, b_trans=True, out=t["dh"])
+            vf.layernorm_bwd(t["dh"], a["x"][i].view(M, D), self.p(pre + "layernorm_before.weight"), a["mean1"][i],
+                             a["rstd1"][i], dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_before.weight"),
+                             dbeta=self.g(pre + "layernorm_before.bias"))
+            dx, dx_other = dx_other, dx
+            if cb:
+                cb(*self.layout.layer_ranges[i])
+        e = "vit.embeddings."
+        dpos = self.g(e + "position_embeddings").view(T, D) if c.pos_encoding_type == "learned" else None
+        vf.embed_finish_bwd(dx.view(B, T, D), self.g(e + "cls_token").view(D), dpos, dropout=(ph, seed, 0),
+                            dpatch=t["dpatch"])
+        vf.colsum(t["dpatch"], out=self.g(e + "patch_embeddings.projection.bias"))
+        vf.gemm(t["dpatch"], a["patches"], M=D, N=P, K=B * N, a_trans=True, b_trans=True,
+                out=self.g(e + "patch_embeddings.projection.weight").view(D, P), split_k=-1)
+        if cb:
+            cb(self.layout.embed_start, self.layout.embed_end)

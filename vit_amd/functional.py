@@ -67,7 +67,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
     d.split_k = split_k
     d.accumulate = int(accumulate)
     if split_k != 0 and split_k != 1:
-        h.ensure_workspace(64 * M * N * 4 if split_k < 0 else split_k * M * N * 4)
+        if split_k < 0:  # same rule as gemm_launch's automatic choice
+            tiles = -(-M // 128) * -(-N // 128)
+            ktiles = -(-K // 64)
+            split_k = min(max(1, 512 // tiles), max(1, ktiles // 4)) if tiles < 256 else 1
+        h.ensure_workspace(split_k * M * N * 4)
+        split_k = d.split_k
     check(h.lib.vit_gemm(h.h, C.byref(d), _stream(a)), "vit_gemm")
     return out
 
@@ -95,14 +100,14 @@ def linear_bwd_dw(dy, x, *, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
-def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, out=None, want_stats: bool = True):
+def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, out=None, mean=None, rstd=None):
     _chk(x, torch.float32, "layernorm_fwd x")
     h = _h(x)
     D = x.shape[-1]
     rows = x.numel() // D
     y = out if out is not None else torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
-    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    mean = mean if mean is not None else torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = rstd if rstd is not None else torch.empty(rows, dtype=torch.float32, device=x.device)
     check(h.lib.vit_layernorm_fwd(h.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _DT[y.dtype],
                                   _ptr(mean), _ptr(rstd), rows, D, eps, _stream(x)), "vit_layernorm_fwd")
     return y, mean, rstd

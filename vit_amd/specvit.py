@@ -1,0 +1,217 @@
+"""`MyViT`: drop-in for the reference's model class (src/models/specvit.py:16-115) on MI355X.
+
+Same constructor arguments, `forward(pixel_values, labels=None, output_attentions=None, output_hidden_states=None,
+return_dict=None)` returning an object with `.loss / .logits / .hidden_states / .attentions`, same `.name`,
+`.loss_name`, `compute_loss`, `log_outputs`, `set_preprocessor_trainable`, the same ValueError for a bad task_type, and
+a `state_dict()` whose keys are those of the reference's checkpoints (transformers 4.56 module names), so checkpoints
+move in both directions.  All arithmetic runs in libvit_amd.so; parameters are views of one flat fp32 buffer.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+from typing import Any, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ._cabi import VitError
+from .config import ViTConfig
+from .engine import ViTEngine
+
+__all__ = ["MyViT", "SequenceClassifierOutput", "build_model_name"]
+
+
+@dataclass
+class SequenceClassifierOutput:
+    """Field-compatible with transformers.modeling_outputs.SequenceClassifierOutput (attribute, key and index access)."""
+
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[Tuple[torch.Tensor, ...]] = None
+
+    def to_tuple(self):
+        return tuple(getattr(self, f.name) for f in fields(self) if getattr(self, f.name) is not None)
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else self.to_tuple()[k]
+
+    def get(self, k, default=None):
+        v = getattr(self, k, None)
+        return default if v is None else v
+
+    def keys(self):
+        return [f.name for f in fields(self) if getattr(self, f.name) is not None]
+
+
+def build_model_name(config, model_prefix: str = "ViT", full_config: dict = None) -> str:
+    """Run-name rule of src/models/model_utils.py:9-45."""
+    stride_used = getattr(config, "stride_size", None)
+    stride_tag = int(stride_used) if (stride_used is not None and stride_used) else config.stride_ratio
+    base_name = (f"{model_prefix}_p{config.patch_size}_h{config.hidden_size}_l{config.num_hidden_layers}_"
+                 f"a{config.num_attention_heads}_s{stride_tag}_p{config.proj_fn}")
+    if full_config is not None:
+        noise_level = (full_config.get("noise", {}) or {}).get("noise_level", 0)
+        if noise_level > 0:
+            base_name += f"_nz{str(noise_level).replace('.', '')}"
+    return base_name
+
+
+class _Node(nn.Module):
+    """Structural container: only exists so parameters get the reference's dotted names."""
+
+
+def _trunc_normal_(t: torch.Tensor, std: float):
+    nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class _ViTFunction(torch.autograd.Function):
+    """Whole-model autograd node: forward/backward are the engine's kernel sequences; parameter gradients come back as
+    views of the engine's flat gradient buffer (no copies when .grad is None, i.e. zero_grad(set_to_none=True))."""
+
+    @staticmethod
+    def forward(ctx, model, x, labels, training, *params):
+        eng = model.engine
+        loss, logits, _, _ = eng.forward(x, labels, training=training, need_grad=True)
+        ctx.model = model
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        model = ctx.model
+        eng = model.engine
+        eng.backward(dloss)
+        grads = []
+        for name, p in zip(model._param_names, model._param_list):
+            if not p.requires_grad or name.startswith("vit.pooler."):
+                grads.append(None)  # the pooler output is never used (specvit.py:78): no gradient, as in the reference
+            else:
+                grads.append(eng.g(name))
+        return (None, None, None, None, *grads)
+
+
+class MyViT(nn.Module):
+    """Vision Transformer over 1-D spectra (reference: `MyViT(ViTPreTrainedModel, BaseModel)`)."""
+
+    config_class = ViTConfig
+
+    def __init__(self, config: ViTConfig, loss_name: str = "", model_name: str = "ViT",
+                 preprocessor: Optional[nn.Module] = None, full_config: dict = None) -> None:
+        super().__init__()
+        self.config = config
+        self.task_type = config.task_type
+        if self.task_type not in ("cls", "reg"):
+            raise ValueError(f"Unsupported task_type '{self.task_type}'")  # specvit.py:55
+        if preprocessor is not None:
+            raise NotImplementedError("input preprocessors (ZCA/PCA/attention) are a SURVEY section 8(f) 'next' row")
+        self.preprocessor = None
+        self.engine = ViTEngine(config, loss_name=loss_name)
+        self._loss_name = self.engine.loss_name
+        self._model_name = build_model_name(config, model_name, full_config=full_config)
+        print(f"Creating {self._model_name} model with {self._loss_name} loss")  # basemodule.py:123
+        self._build_tree()
+        self.init_weights()
+
+    # ------------------------------------------------------------------ structure
+    def _build_tree(self):
+        lay = self.engine.layout
+        self._param_names = list(lay.state_order)
+        plist = []
+        for name in self._param_names:
+            parts = name.split(".")
+            node = self
+            for part in parts[:-1]:
+                if part not in node._modules:
+                    node.add_module(part, _Node())
+                node = node._modules[part]
+            prm = nn.Parameter(lay.view(self.engine.flat, name), requires_grad=True)
+            node.register_parameter(parts[-1], prm)
+            plist.append(prm)
+        self._param_list = plist
+        self.engine.version_fn = self._version_signature
+
+    def _version_signature(self) -> int:
+        # in-place updates by torch optimizers / load_state_dict / p.copy_() bump the parameter's version counter
+        return sum(p._version for p in self._param_list) + self.engine.flat._version
+
+    def _rebind_views(self):
+        lay = self.engine.layout
+        for name, prm in zip(self._param_names, self._param_list):
+            prm.data = lay.view(self.engine.flat, name)
+            prm.grad = None
+
+    def _apply(self, fn, recurse=True):
+        """.to()/.cuda()/.cpu(): move the ONE flat buffer and re-point every parameter at its slice."""
+        new_flat = fn(self.engine.flat)
+        self.engine.rebind(new_flat)
+        self._rebind_views()
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        out = super().load_state_dict(state_dict, strict=strict, assign=False)
+        self.engine._shadow_version = -1
+        return out
+
+    @torch.no_grad()
+    def init_weights(self):
+        """HF `_init_weights` as the reference triggers it (specvit.py:57): Linear / Conv weights ~ trunc_normal(0,
+        initializer_range), biases 0, LayerNorm 1/0.  cls_token and learned position_embeddings belong to
+        SpectraEmbeddings (not an HF ViTEmbeddings), so they keep their torch.randn values (embedding.py:47,62-64)."""
+        std = self.config.initializer_range
+        for name, p in zip(self._param_names, self._param_list):
+            if name.endswith("cls_token") or name.endswith("position_embeddings"):
+                p.copy_(torch.randn(p.shape))
+            elif "layernorm" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif name.endswith("bias"):
+                p.zero_()
+            else:
+                _trunc_normal_(p, std)
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def name(self):
+        return self._model_name
+
+    @property
+    def loss_name(self):
+        return self._loss_name
+
+    def forward(self, pixel_values, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None):
+        eng = self.engine
+        training = self.training
+        want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self._param_list)
+        if want_grad and not (output_attentions or output_hidden_states):
+            loss, logits = _ViTFunction.apply(self, pixel_values, labels, training, *self._param_list)
+            hs = atts = None
+        else:
+            with torch.no_grad():
+                loss, logits, hs, atts = eng.forward(pixel_values, labels, training=training, need_grad=False,
+                                                     output_hidden_states=bool(output_hidden_states),
+                                                     output_attentions=bool(output_attentions))
+        out = SequenceClassifierOutput(loss=loss, logits=logits,
+                                       hidden_states=tuple(hs) if hs is not None else None,
+                                       attentions=tuple(atts) if atts is not None else None)
+        if return_dict is False:
+            return out.to_tuple()
+        return out
+
+    def compute_loss(self, *args, **kwargs):
+        return self.forward(*args, **kwargs).loss
+
+    def log_outputs(self, outputs, log_fn=print, stage: str = ""):
+        loss = outputs.get("loss") if isinstance(outputs, dict) else getattr(outputs, "loss", None)
+        if loss is not None:
+            log_fn({f"{self.loss_name}_loss": loss})
+
+    def set_preprocessor_trainable(self, trainable: bool) -> None:
+        if self.preprocessor is None:
+            return
+
+    # ------------------------------------------------------------------ extras used by the build's own trainer
+    def flat_parameters(self) -> torch.Tensor:
+        return self.engine.flat
+
+    def flat_gradients(self) -> torch.Tensor:
+        return self.engine.grads
