@@ -87,7 +87,9 @@ def main():
         "noise": {"noise_level": 0},
     }
     seed_everything(42)  # scripts/run.py:22,28
-    module = ViTLModule(config=config)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
+        module = ViTLModule(config=config)
     trainer = Trainer(config["train"], device=dev, verbose=False)
     trainer._setup(module)
     module.train()

@@ -1,0 +1,83 @@
+"""CPU suite: the N>1 path (bucketed mean all-reduce of the flat gradient buffer, parameter broadcast, sample
+sharding) with world_size 2 over gloo."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from vit_amd import ddp as d
+    from vit_amd.config import ViTConfig
+    from vit_amd.engine import ParamLayout
+
+    r, lr, w = d.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = ViTConfig(task_type="reg", image_size=256, patch_size=32, hidden_size=32, num_hidden_layers=2,
+                    num_attention_heads=2, stride_size=32)
+    lay = ParamLayout(cfg)
+    # parameter broadcast: every rank ends with rank 0's values
+    flat = torch.full((lay.n_total,), float(rank + 1))
+    d.broadcast_parameters(flat)
+    assert torch.all(flat == 1.0)
+    # bucketed mean all-reduce in backward-completion order, with a small max bucket to force splitting
+    g = torch.arange(lay.n_total, dtype=torch.float32) * (rank + 1)
+    red = d.GradAllReducer(lambda: g, lay.buckets(), max_bucket_elems=1000)
+    for lo, hi in lay.buckets():
+        red.bucket_ready(lo, hi)
+    red.finish()
+    expect = torch.arange(lay.n_total, dtype=torch.float32) * (1 + 2) / 2
+    n = lay.n_trainable
+    ok = torch.allclose(g[:n], expect[:n])
+    # the pooler slice (never has a gradient) is in no bucket and must be left alone
+    ok = ok and torch.equal(g[n:], torch.arange(lay.n_total, dtype=torch.float32)[n:] * (rank + 1))
+    covered = sorted(lay.buckets())
+    ok = ok and covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    idx = d.shard_indices(11, rank, world, epoch=3, shuffle=True, seed=42)
+    q.put((rank, bool(ok), idx.tolist(), red.bytes_reduced))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_broadcast_and_sharding_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    a, b = res[0][2], res[1][2]
+    assert len(a) == len(b) == 6 and set(a + b) == set(range(11))  # padded by wrapping, like DistributedSampler
+    assert res[0][3] > 0
+
+
+def test_bucket_order_matches_backward():
+    from vit_amd.config import ViTConfig
+    from vit_amd.engine import ParamLayout
+
+    cfg = ViTConfig(task_type="cls", image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=3,
+                    num_attention_heads=2, stride_size=32, num_labels=5, pos_encoding_type="learned")
+    lay = ParamLayout(cfg)
+    b = lay.buckets()
+    assert b[0] == (lay.tail_start, lay.n_trainable)          # final LN + head finish first
+    assert b[1:4] == list(reversed(lay.layer_ranges))           # then layers L-1 .. 0
+    assert b[4] == (lay.embed_start, lay.embed_end)             # embeddings last
+    assert lay.entries["vit.pooler.dense.weight"][0] >= lay.n_trainable

@@ -1,0 +1,164 @@
+"""CPU suite (-m "not gpu"): the oracle against the golden vectors generated from the reference's own modules, the
+config mapping, and the host-side model surface (names, shapes, state_dict, errors).  No kernel runs here."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refvit
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CONFIGS = {
+    "c1": lambda: refvit.named_config("C1"),
+    "c2": lambda: refvit.named_config("C2"),
+    "r1": lambda: refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2,
+                                   num_attention_heads=4, stride_size=48, num_labels=3, loss_name="l1"),
+    "k1": lambda: refvit.RefConfig(image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=2,
+                                   num_attention_heads=2, stride_size=32, task_type="cls", num_labels=5,
+                                   pos_encoding_type="learned", loss_name="ce"),
+}
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("tag", sorted(CONFIGS))
+def test_oracle_reproduces_reference_golden(tag):
+    """The restatement must reproduce what the reference's modules produced (fixtures written by oracle/make_golden.py)."""
+    rc = CONFIGS[tag]()
+    g = np.load(os.path.join(GOLD, f"{tag}.npz"))
+    sd = refvit.make_state_dict(rc, int(g["wseed"]))
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["weight_checksum"])) < 1e-6
+    x, labels = torch.from_numpy(g["flux"]), torch.from_numpy(g["labels"])
+    with torch.no_grad():
+        out = refvit.forward(rc, sd, x, labels, output_hidden_states=True, output_attentions=True)
+    assert rel(out.tokens, g["tokens"]) < 1e-5
+    assert rel(out.last_hidden_state, g["last_hidden_state"]) < 1e-5
+    assert rel(out.logits, g["logits"]) < 1e-5
+    assert abs(float(out.loss) - float(g["loss"])) < 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert rel(torch.stack(out.hidden_states), g["hidden_states"]) < 1e-5
+    assert rel(out.attentions[0], g["attn0"]) < 1e-5 and rel(out.attentions[-1], g["attn_last"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["c1", "r1", "k1"])
+def test_oracle_gradients_and_steps(tag):
+    rc = CONFIGS[tag]()
+    g = np.load(os.path.join(GOLD, f"{tag}.npz"))
+    sd = refvit.make_state_dict(rc, int(g["wseed"]))
+    x, labels = torch.from_numpy(g["flux"]), torch.from_numpy(g["labels"])
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    refvit.forward(rc, tr.params, x, labels).loss.backward()
+    for k, p in tr.params.items():
+        if f"grad/{k}" not in g.files:
+            assert p.grad is None  # pooler
+            continue
+        ref = torch.from_numpy(g[f"grad/{k}"])
+        if float(ref.norm()) < 1e-6:
+            continue
+        assert rel(p.grad, ref) < 1e-4, k
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    losses = [tr.step(x, labels) for _ in range(3)]
+    assert np.allclose(losses, g["step_losses"], rtol=1e-4)
+    after = tr.state_dict()
+    for k in sd:
+        if f"after3/{k}" in g.files and "key.bias" not in k:
+            assert rel(after[k], g[f"after3/{k}"]) < 1e-4, k
+
+
+def test_ragged_tail_patch_is_all_zero():
+    """tokenization.py:43-50: unfold drops the partial window; the missing patch is zero-filled, so its token == bias."""
+    rc = CONFIGS["r1"]()
+    assert rc.num_patches == math.ceil((1000 - 64) / 48) + 1 == 21
+    sd = refvit.make_state_dict(rc, 1)
+    x, _, _ = refvit.make_inputs(rc, 2, 2)
+    tok = refvit.tokenize(rc, sd, x)
+    b = sd["vit.embeddings.patch_embeddings.projection.bias"]
+    assert torch.allclose(tok[:, -1], b.expand(2, -1))
+
+
+def test_loss_resolution_matches_reference_rule():
+    """specvit.py:52-53: 'mae' does not contain 'l1' -> MSELoss; 'l1'/'L1Loss' -> L1."""
+    mk = lambda name, task="reg": refvit.RefConfig(image_size=64, patch_size=32, hidden_size=32, num_hidden_layers=1,
+                                                   num_attention_heads=2, loss_name=name, task_type=task)
+    assert refvit.resolved_loss(mk("mae")) == "mse"
+    assert refvit.resolved_loss(mk("")) == "mse"
+    assert refvit.resolved_loss(mk("L1")) == "l1"
+    assert refvit.resolved_loss(mk("whatever", "cls")) == "ce"
+
+
+def test_get_vit_config_rules():
+    from vit_amd.config import get_vit_config
+
+    cfg = {"model": dict(task_type="reg", image_size=4096, patch_size=32, hidden_size=32, num_hidden_layers=3,
+                         num_attention_heads=2, stride_size=32, proj_fn="SW", num_labels=7),
+           "data": {"param": "Teff, log_g ,M_H"}}
+    vc = get_vit_config(cfg)
+    assert vc.num_labels == 3 and cfg["model"]["num_labels"] == 3  # derived from data.param, written back
+    assert vc.intermediate_size == 128 and vc.layer_norm_eps == 1e-12 and vc.hidden_dropout_prob == 0.1
+    assert vc.num_patches == 128 and vc.seq_len == 129
+    rc = refvit.config_from_dict({"model": dict(cfg["model"]), "data": cfg["data"], "loss": {"name": "mae"}})
+    assert (rc.num_labels, rc.num_patches, rc.intermediate_size) == (3, 128, 128)
+    cfg2 = {"model": dict(task_type="cls", image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=1,
+                          num_attention_heads=2, proj_fn="C1D", num_labels=5, stride_ratio=0.5)}
+    vc2 = get_vit_config(cfg2)
+    assert vc2.num_labels == 5 and vc2.stride == 16 and vc2.num_patches == (512 - 32) // 16 + 1
+
+
+def test_model_surface_on_cpu():
+    """Construction, names, parameter count, state_dict round trip and the reference's error behaviour -- no GPU."""
+    from vit_amd._cabi import VitError
+    from vit_amd.builder import get_model
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    cfg = {"model": dict(name="vit", task_type="reg", image_size=4096, patch_size=32, hidden_size=32,
+                         num_hidden_layers=3, num_attention_heads=2, stride_size=32, proj_fn="SW"),
+           "loss": {"name": "mae"}, "data": {"param": "log_g"}, "noise": {"noise_level": 0.1}}
+    m = get_model(cfg)
+    assert sum(p.numel() for p in m.parameters()) == 40353
+    assert m.name == "ViT_p32_h32_l3_a2_s32_pSW_nz01" and m.loss_name == "mae"
+    rc = refvit.named_config("C1")
+    assert list(m.state_dict().keys()) == list(refvit.param_shapes(rc).keys()) or \
+        sorted(m.state_dict().keys()) == sorted(refvit.param_shapes(rc).keys())
+    for k, shape in refvit.param_shapes(rc).items():
+        assert tuple(m.state_dict()[k].shape) == tuple(shape), k
+    sd = refvit.make_state_dict(rc, 3)
+    m.load_state_dict(sd)
+    assert all(torch.equal(m.state_dict()[k], sd[k]) for k in sd)
+    # q/k/v weights are adjacent in the flat buffer (the fused QKV projection reads them as one [3D, D] matrix)
+    lay = m.engine.layout
+    o = [lay.entries[f"vit.encoder.layer.0.attention.attention.{n}.weight"][0] for n in ("query", "key", "value")]
+    assert o[1] - o[0] == 32 * 32 and o[2] - o[1] == 32 * 32
+    with pytest.raises(VitError):
+        m(torch.zeros(2, 4096), labels=torch.zeros(2))  # no CPU fallback
+    with pytest.raises(ValueError):
+        MyViT(ViTConfig(task_type="seg", image_size=64, patch_size=32, hidden_size=32, num_hidden_layers=1,
+                        num_attention_heads=2))
+    with pytest.raises(ValueError):
+        MyViT(ViTConfig(task_type="reg", image_size=64, patch_size=32, hidden_size=32, num_hidden_layers=1,
+                        num_attention_heads=2, proj_fn="XYZ"))
+    with pytest.raises(ValueError):
+        get_model({"model": dict(cfg["model"]), "warmup": {"preprocessor": "zca"}})  # builder.py:155
+
+
+def test_optmodule_mirrors_reference_config_handling():
+    from vit_amd.optimizer import OptModule
+
+    om = OptModule.from_config({"type": "AdamW", "lr": 0.001, "lr_sch": "plateau", "factor": 0.8, "patience": 10,
+                                "monitor_metric": "mae"})
+    assert om.opt_type == "adamw" and om.lr_scheduler_name == "plateau" and om.kwargs == {"factor": 0.8, "patience": 10}
+    lin = torch.nn.Linear(4, 4)
+    conf = om(lin)
+    assert isinstance(conf["optimizer"], torch.optim.AdamW) and conf["optimizer"].defaults["weight_decay"] == 0
+    assert conf["lr_scheduler"]["monitor"] == "val_mae" and conf["lr_scheduler"]["reduce_on_plateau"] is True
+    om2 = OptModule.from_config({"lr": 1e-3, "lr_sch": "cosine", "ep": 40, "warmup": {"epochs": 2}})
+    conf2 = om2(lin)
+    assert conf2["lr_scheduler"]["interval"] == "epoch"
+    assert isinstance(conf2["lr_scheduler"]["scheduler"], torch.optim.lr_scheduler.SequentialLR)
+    with pytest.raises(ValueError):
+        OptModule(lr=1e-3, lr_scheduler_name="nope")(lin)

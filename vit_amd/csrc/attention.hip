@@ -29,7 +29,7 @@ constexpr float LN2 = 0.6931471805599453f;
 
 struct AttnArgs {
   const short* qkv; short* ctx; float* lse;
-  const short* dctx; const float* delta; short* dqkv;
+  const short* dctx; float* delta; short* dqkv;
   int B, H, T, dh;
   float scale;
   DropCfg drop;
@@ -199,27 +199,6 @@ __global__ __launch_bounds__(AW * 64) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ delta
-// delta[bh, q] = sum_d ctx[b, q, h, d] * dctx[b, q, h, d]; one thread per (row, head)
-__global__ void attn_delta_kernel(const short* __restrict__ ctx, const short* __restrict__ dctx,
-                                  float* __restrict__ delta, int B, int H, int T, int dh) {
-  const long n = (long)B * T * H;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const int h = (int)(i % H);
-    const long row = i / H;  // b*T + q
-    const short* a = ctx + row * (H * dh) + h * dh;
-    const short* g = dctx + row * (H * dh) + h * dh;
-    float s = 0.f;
-    for (int d = 0; d < dh; d += 8) {
-      const bf16x8 x = *(const bf16x8*)(a + d), y = *(const bf16x8*)(g + d);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s += bf2f(x[k]) * bf2f(y[k]);
-    }
-    const long b = row / T, q = row - b * T;
-    delta[(b * H + h) * T + q] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH>
 __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -242,7 +221,24 @@ __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
   load_own<DH>(dof, dob, ldc, q0, T, dh, l15, lg);
   const float c = p.scale * LOG2E;
   const float lse2 = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
-  const float del = q < T ? p.delta[(long)bh * T + q] : 0.f;
+  // delta[q] = rowsum(dO * O): this lane holds 8 columns per 32-column step of its row; the 4 lane groups complete the
+  // row with two xor-shuffles.  Written out for the dK/dV kernel that runs next on the stream.
+  float del = 0.f;
+  {
+    const short* ob = p.ctx + (long)b * T * ldc + h * dh;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      const int col = s * 32 + lg * 8;
+      if (q < T && col < dh) {
+        const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) del += bf2f(o[e]) * bf2f(dof[s][e]);
+      }
+    }
+    del += __shfl_xor(del, 16, 64);
+    del += __shfl_xor(del, 32, 64);
+    if (q < T && lg == 0) p.delta[(long)bh * T + q] = del;
+  }
   f32x4 dqt[DH / 16];
 #pragma unroll
   for (int i = 0; i < DH / 16; ++i) dqt[i] = zero4();
@@ -484,12 +480,8 @@ int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void
   int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
   if (rc != VIT_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const long n = (long)B * T * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, st,
-                     (const short*)ctx, (const short*)dctx, delta, B, H, T, dh);
-  VIT_LAUNCH_CHECK();
   AttnArgs a = {};
-  a.qkv = (const short*)qkv; a.lse = const_cast<float*>(lse);
+  a.qkv = (const short*)qkv; a.lse = const_cast<float*>(lse); a.ctx = (short*)const_cast<void*>(ctx);
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);

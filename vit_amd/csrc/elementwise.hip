@@ -141,14 +141,39 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restri
     *(f32x4*)(part + (long)blockIdx.y * cols + c) = s;
   }
 }
-__global__ void colsum_stage2_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int cols,
-                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float a = 0.f;
-  for (int k = 0; k < nchunk; ++k) a += part[(long)k * cols + c];
-  if (accumulate) a += out[c];
-  out[c] = a;
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int width,
+                                                               float* __restrict__ out0, int split,
+                                                               float* __restrict__ out1, int accumulate) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < width) {
+    int k = ty;
+    for (; k + 16 < nblk; k += 32) {
+      a0 += part[(long)k * width + c];
+      a1 += part[(long)(k + 16) * width + c];
+    }
+    if (k < nblk) a0 += part[(long)k * width + c];
+  }
+  red[ty][tx] = a0 + a1;
+  __syncthreads();
+  if (ty == 0 && c < width) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][tx];
+    float* o = c < split ? out0 + c : out1 + (c - split);
+    if (accumulate) s += *o;
+    *o = s;
+  }
+}
+
+int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(width, 64)), dim3(1024), 0, st, part, nblk, width, out0, split,
+                     out1, accumulate);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
 }
 
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, short* __restrict__ dst, long n) {
@@ -398,9 +423,7 @@ int vit_colsum(vit_handle h, const void* a, int a_dtype, int64_t lda, float* out
   else
     hipLaunchKernelGGL(colsum_stage1_kernel<0>, dim3(gx, gy), dim3(256), 0, st, a, (long)lda, part, rows, cols);
   VIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, part, out, gy, cols, accumulate);
-  VIT_LAUNCH_CHECK();
-  return VIT_OK;
+  return launch_reduce_partials(part, gy, cols, out, cols, out, accumulate, st);
 }
 
 int vit_cast_f32_bf16(vit_handle h, const float* src, void* dst, int64_t n, vit_stream stream) {

@@ -141,18 +141,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-// out[c] (+)= sum_blk part[blk][c]; part rows have `width` floats
-__global__ void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1,
-                                   int nblk, int D, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * D) return;
-  float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += part[(long)b * 2 * D + i];
-  float* o = (i < D) ? (out0 + i) : (out1 + (i - D));
-  if (accumulate) a += *o;
-  *o = a;
-}
-
 template <int OUT_BF16>
 static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
                            int D, float eps, hipStream_t st) {
@@ -218,9 +206,7 @@ int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x
   int rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st)
                                 : ln_bwd_dispatch<0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st);
   if (rc != VIT_OK) return rc;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, st, part, dgamma, dbeta, blocks, D, 0);
-  VIT_LAUNCH_CHECK();
-  return VIT_OK;
+  return launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st);
 }
 
 }  // extern "C"
