@@ -42,6 +42,12 @@ const char* vit_last_error(void);
 int vit_create(vit_handle* out, int device);
 int vit_destroy(vit_handle h);
 int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
+/* Process-wide tuning / diagnostics knobs (never change results beyond rounding order):
+ *   "gemm_core": 0 = generic 128x128 core only, 1 = automatic (default); on tile-aligned problems 2 / 3 / 4 force the
+ *                LDS-DMA core's 256x256xBK64 (2 stages) / 256x128xBK64 (3 stages) / 256x256xBK32 (4 stages) geometry,
+ *                5 the staggered 256x256xBK32 variant (wave halves alternate LOAD and MFMA roles).
+ *                Returns VIT_ERR_ARG for an unknown name. */
+int vit_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
  * C = epilogue(alpha * op(A) * op(B)), bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.

@@ -349,3 +349,91 @@ def test_sqnorm_adamw(dev):
         vf.adamw_step(p, gs, m, v, pb, lr=1e-3, weight_decay=0.01, step=step, sqnorm=sq, max_norm=0.5)
         assert rel(p, pt.detach()) < 1e-6
     assert torch.equal(pb, bf(p))
+
+
+# ------------------------------------------------------------------ the LDS-DMA / persistent GEMM core (gemm2.hip)
+ALIGNED = [(256, 128, 64), (512, 256, 128), (1024, 768, 768), (2304, 768, 256), (768, 3072, 768), (1792, 2304, 768)]
+
+
+@pytest.mark.parametrize("core", [2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", ALIGNED)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+def test_gemm2_layouts(dev, core, M, N, K, layout):
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    a_t, b_t = layout in ("tn", "tt"), layout in ("nn", "tn")
+    A, Bm = bf(randn((M, K), dev, 1)), bf(randn((N, K), dev, 2))
+    ref = A.float() @ Bm.float().t()
+    a_store = A.t().contiguous() if a_t else A
+    b_store = Bm.t().contiguous() if b_t else Bm
+    _cabi.set_option("gemm_core", core)
+    try:
+        out = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.float32)
+        out16 = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.bfloat16)
+        sk = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.float32, split_k=-1)
+    finally:
+        _cabi.set_option("gemm_core", 1)
+    assert rel(out, ref) < 2e-5, (layout, rel(out, ref))
+    assert rel(out16, ref) < 4e-3
+    assert rel(sk, ref) < 2e-5
+
+
+@pytest.mark.parametrize("core", [0, 2, 3, 4, 5])
+def test_gemm2_epilogues_match_generic_core(dev, core):
+    """Every fused epilogue on a tile-aligned problem, each core against the torch reference (and so against each other)."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+    from vit_amd._cabi import ACT_GELU
+
+    M, N, K = 1024, 768, 512
+    x, W = bf(randn((M, K), dev, 3)), bf(randn((N, K), dev, 4, 0.1))
+    bias, res = randn((N,), dev, 5), randn((M, N), dev, 6)
+    base = x.float() @ W.float().t() + bias
+    _cabi.set_option("gemm_core", core)
+    try:
+        aux = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        y = vf.linear_fwd(x, W, bias, act=ACT_GELU, aux_out=aux)
+        assert rel(aux, base) < 4e-3 and rel(y, F.gelu(base)) < 5e-3
+        y = vf.linear_fwd(x, W, bias, out_dtype=torch.float32, residual=res)
+        assert rel(y, base + res) < 2e-5
+        drop = (0.1, 77, 5)
+        yd = vf.linear_fwd(x, W, bias, out_dtype=torch.float32, dropout=drop, residual=res)
+        mask = vf.dropout_bwd_cast(torch.ones((M, N), device=dev), drop).float()
+        assert rel(yd, base * mask + res) < 5e-3  # mask scale is bf16-rounded in this reconstruction
+        assert torch.equal((yd - res).abs() > 1e-6, mask != 0) or ((yd - res != 0) == (mask != 0)).float().mean() > 0.999
+        dy, u = bf(randn((M, N), dev, 7)), bf(randn((M, K), dev, 8))
+        dx = vf.linear_bwd_dx(dy, W, dgelu_aux=u, out_dtype=torch.float32)
+        uu = u.float().requires_grad_(True)
+        F.gelu(uu).backward(dy.float() @ W.float())
+        assert rel(dx, uu.grad) < 2e-5
+        dw = vf.linear_bwd_dw(dy, x)
+        assert rel(dw, dy.float().t() @ x.float()) < 2e-5
+        dw2 = vf.linear_bwd_dw(dy, x, out=dw.clone(), accumulate=True)
+        assert rel(dw2, 2 * (dy.float().t() @ x.float())) < 2e-5
+        # patch-embed shaped row map: M = B * N rows -> rows 1..N of each sample
+        Bn, rpb = 8, 96   # 768 rows
+        xx = bf(randn((Bn * rpb, K), dev, 9))
+        out = torch.full((Bn * (rpb + 1), N), 7.0, dtype=torch.float32, device=dev)
+        vf.gemm(xx, W, M=Bn * rpb, N=N, K=K, out=out, bias=bias, row_map=(rpb, rpb + 1, 1))
+        ref = (xx.float() @ W.float().t() + bias).view(Bn, rpb, N)
+        o3 = out.view(Bn, rpb + 1, N)
+        assert rel(o3[:, 1:], ref) < 2e-5 and torch.all(o3[:, 0] == 7.0)
+    finally:
+        _cabi.set_option("gemm_core", 1)
+
+
+def test_gemm2_many_tiles_persistent(dev):
+    """More tiles than CUs (several persistent rounds, partial last round) and bitwise run-to-run determinism."""
+    import vit_amd.functional as vf
+
+    M, N, K = 256 * 37, 768, 256   # 111 or 222 tiles
+    a, b = bf(randn((M, K), dev, 12)), bf(randn((N, K), dev, 13))
+    ref = a.float() @ b.float().t()
+    o1 = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32)
+    o2 = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32)
+    assert rel(o1, ref) < 2e-5 and torch.equal(o1, o2)
+    M = 256 * 300                    # 900 / 1800 tiles: > 3 rounds on 256 CUs
+    a = bf(randn((M, K), dev, 14))
+    o = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32)
+    assert rel(o, a.float() @ b.float().t()) < 2e-5

@@ -52,6 +52,7 @@ _PROTOS = {
     "vit_create": [C.POINTER(_P), _I],
     "vit_destroy": [_P],
     "vit_set_workspace": [_P, _P, _SZ],
+    "vit_set_option": [C.c_char_p, _I],
     "vit_gemm": [_P, C.POINTER(GemmDesc), _P],
     "vit_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _U64, _U64, _P, _P],
     "vit_linear_bwd_dx": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
@@ -106,6 +107,10 @@ def load():
             fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = lib
         return lib
+
+
+def set_option(name: str, value: int):
+    check(load().vit_set_option(name.encode(), int(value)), f"vit_set_option({name})")
 
 
 def check(rc: int, what: str = ""):

@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "_build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvit_amd.so")
 ARCH = "gfx950"
-SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm2.hip", "layernorm.hip", "attention.hip", "elementwise.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "vit_amd.h")]
 
 

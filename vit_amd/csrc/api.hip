@@ -13,6 +13,8 @@ struct vit_ctx {
 
 namespace vit {
 
+extern int g_gemm2_mode;  // gemm2.hip
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {
@@ -59,6 +61,17 @@ int vit_create(vit_handle* out, int device) {
 int vit_destroy(vit_handle h) {
   delete h;
   return VIT_OK;
+}
+
+int vit_set_option(const char* name, int value) {
+  VIT_CHECK(name, VIT_ERR_ARG, "vit_set_option: null name");
+  if (strcmp(name, "gemm_core") == 0) {
+    VIT_CHECK(value >= 0 && value <= 5, VIT_ERR_ARG, "vit_set_option: gemm_core must be 0..5");
+    vit::g_gemm2_mode = value;
+    return VIT_OK;
+  }
+  vit::set_error("vit_set_option: unknown option '%s'", name);
+  return VIT_ERR_ARG;
 }
 
 int vit_set_workspace(vit_handle h, void* ws, size_t bytes) {

@@ -58,15 +58,12 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 // thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr) so the mask is exactly unbiased.
 // The reference's own masks come from torch's Philox stream and are implementation-defined (they differ between
 // its CPU and CUDA runs too), so only the distribution is part of the contract.
-__device__ __forceinline__ unsigned lowbias32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
 __device__ __forceinline__ unsigned drop_hash(unsigned k0, unsigned k1, unsigned long long pair_idx) {
-  unsigned lo = (unsigned)pair_idx, hi = (unsigned)(pair_idx >> 32);
-  unsigned x = lowbias32(lo ^ k0);
-  x ^= k1 + hi * 0x9E3779B9u;
-  return lowbias32(x);
+  // one round of the "lowbias32" integer finaliser (xorshift-multiply x2) keyed on both ends: 8 integer ops per PAIR of
+  // elements -- the fused GEMM epilogues are VALU-bound, so the mask generator has to be this cheap
+  unsigned x = (unsigned)pair_idx ^ k0 ^ ((unsigned)(pair_idx >> 32) * 0x9E3779B9u);
+  x ^= x >> 16; x *= 0x7feb352du; x += k1; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
 }
 struct DropCfg {
   unsigned thr;   // 0 => dropout off
@@ -95,12 +92,30 @@ __device__ __forceinline__ void drop_pair(const DropCfg& d, unsigned long long r
   m1 = ((h >> 16) >= d.thr) ? d.scale : 0.f;
 }
 
-// ---- exact-erf GELU (HF hidden_act="gelu", src/models/builder.py:246) ---------------------------------
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// ---- erf GELU (HF hidden_act="gelu", src/models/builder.py:246): 0.5 x (1 + erf(x / sqrt 2)) ---------------------
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-rounding level and 4 orders below bf16 resolution):
+// one v_rcp + one v_exp + 6 FMAs instead of libm's branchy erff (the GELU epilogue of the FC1 GEMM was VALU-bound).
+// cdf(x) = Phi(x) and pdf-exponential e^{-x^2/2} share the same exponential, so gelu' costs no second transcendental.
+__device__ __forceinline__ void phi_parts(float x, float& cdf, float& ex) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  ex = __expf(-z * z);  // = e^{-x^2/2}
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float half_erfc = 0.5f * poly * t * ex;     // 0.5 * erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf, ex;
+  phi_parts(x, cdf, ex);
+  return x * cdf;
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, ex;
+  phi_parts(x, cdf, ex);
+  return fmaf(x * 0.39894228040143267794f, ex, cdf);
 }
 
 // ---- wave reductions ---------------------------------------------------------------------------

@@ -285,8 +285,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
   }
 }
 
-struct Ctx;
 void* ctx_workspace(vit_handle h, size_t* bytes);
+int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* rc);  // gemm2.hip
+
+int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, int splits, float alpha, int accumulate,
+                         hipStream_t st) {
+  const long nvec = (long)M * (N / 4);
+  const int blocks = (int)std::min<long>((nvec + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, slab, C, ldc, M, N, splits, alpha, accumulate);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -312,6 +321,12 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   if (d->act == VIT_ACT_DGELU) VIT_CHECK(d->aux_in && (d->ldaux % 4) == 0, VIT_ERR_ARG, "vit_gemm: ACT_DGELU needs aux_in");
   if (d->aux_out) VIT_CHECK((d->ldaux % 4) == 0 && d->ldaux >= d->N, VIT_ERR_ARG, "vit_gemm: bad ldaux");
   VIT_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f, VIT_ERR_ARG, "vit_gemm: dropout_p out of [0,1)");
+
+  if (d->dropout_p > 0.f) VIT_CHECK((d->N % 2) == 0, VIT_ERR_ARG, "vit_gemm: dropout needs an even N");
+  {
+    int rc2 = VIT_OK;  // tile-aligned problems go to the LDS-DMA / persistent core
+    if (gemm2_try_launch(h, d, st, &rc2)) return rc2;
+  }
 
   GemmArgs a;
   a.A = (const char*)d->A; a.B = (const char*)d->B; a.C = (char*)d->C;
@@ -365,13 +380,8 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
     default: hipLaunchKernelGGL((gemm_bf16_kernel<1, 1>), grid, block, 0, st, a); break;
   }
   VIT_LAUNCH_CHECK();
-  if (splits > 1) {
-    const long nvec = (long)d->M * (d->N / 4);
-    int blocks = (int)std::min<long>((nvec + 255) / 256, 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.slab, (float*)d->C, (long)d->ldc, d->M,
-                       d->N, splits, d->alpha, d->accumulate);
-    VIT_LAUNCH_CHECK();
-  }
+  if (splits > 1)
+    return launch_splitk_reduce(a.slab, (float*)d->C, (long)d->ldc, d->M, d->N, splits, d->alpha, d->accumulate, st);
   return VIT_OK;
 }
 

@@ -1,0 +1,545 @@
+// Second-generation bf16 MFMA GEMM core for gfx950, used when the problem is tile-aligned (the ViT-B / ViT-L shapes
+// are: M = B*T = 197*256, N and K multiples of 256 / 64).  Same contract, operand layouts, MFMA operand maps and fused
+// epilogues as gemm.hip; what changes is how operands reach the LDS, how long they may be in flight, and how results
+// leave the CU:
+//
+//   * 256-row tiles (256x256 or 256x128), 8 waves = 512 threads, one workgroup per CU;
+//   * LDS-DMA staging: __builtin_amdgcn_global_load_lds(.., 16, ..) writes 1 KiB per wave-instruction straight into a
+//     ring of NSTAGE stages, no staging registers.  The DMA destination is lane-linear, so the XOR swizzle of both
+//     image kinds is applied to the per-lane SOURCE address and to the fragment reads (never to the destination);
+//   * counted waits: K-tile `it` is awaited with s_waitcnt vmcnt((NSTAGE-2) * loads_per_tile) + one raw s_barrier per
+//     K-tile, so NSTAGE-1 K-tiles stay in flight across barriers (measured: with one tile in flight the waves sat in
+//     s_waitcnt ~50 % of the time).  Default geometry BK = 32, 4 stages: 3 K-tiles = 96 KiB in flight per CU;
+//   * persistent over output tiles: a workgroup walks its tiles in one flat (tile, k-tile) iteration space, so the
+//     loads of the next tile's first K-tiles are already in flight during the current tile's epilogue;
+//   * XCD-aware tile order inside each round of concurrently running tiles (neighbours in n share the A panel in L2);
+//   * epilogue through a per-wave LDS transpose (the 32 KiB / 16 KiB the ring leaves free): accumulators go to LDS in
+//     MFMA layout and come back row-major, so every bias / aux / residual load and every output store of a
+//     wave-instruction covers whole 128- or 256-byte row segments instead of 16 rows x 32 bytes.
+//
+// LDS images (byte offsets inside one operand image of R rows):
+//   K-contiguous, BK=64: row r, 16-B chunk c at r*128 + ((c ^ ((r>>1)&7)) << 4)
+//   K-contiguous, BK=32: row r, 16-B chunk c at r*64  + ((c ^ ((-(r>>2))&3)) << 4)
+//   transposed:          k-row k, 8-B chunk ch at k*2R + ((ch ^ tr_swz(k)) << 3),  tr_swz(k) = ((k&3) | ((k>>3)&1)<<2) << 2
+// all conflict-free for the 16x16x32 operand reads (ds_read_b128 / ds_read_b64_tr_b16): SQ_LDS_BANK_CONFLICT = 0.
+#include <algorithm>
+
+#include "common.h"
+
+namespace vit {
+
+#define GLB_AS __attribute__((address_space(1)))
+
+struct Gemm2Args {
+  const char* A; const char* B; char* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int tiles_m, tiles_n, nblk;
+  int splits, k_per_split;
+  float* slab;
+  const float* bias;
+  const short* aux_in; short* aux_out; long ldaux;
+  const float* residual; long ldres;
+  float alpha;
+  int act, c_dtype;
+  DropCfg drop;
+  int rpb, orb, roff;
+};
+
+__device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
+
+// per-thread DMA source offset (elements) of round i for one operand image; destination = i*8192 + wave*1024 + lane*16
+template <int TRANS, int R, int BK>
+__device__ __forceinline__ int dma_src_off(int i, int wave, int lane, int ld) {
+  if (TRANS == 0) {
+    if (BK == 64) {
+      const int row = i * 64 + wave * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      return row * ld + c * 8;
+    } else {
+      const int row = i * 128 + wave * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+      return row * ld + c * 8;
+    }
+  } else {
+    constexpr int RB = R * 2, LPR = RB / 16;
+    const int k = i * (8192 / RB) + wave * (1024 / RB) + lane / LPR;
+    const int c16 = (lane % LPR) ^ (tr_swz2(k) >> 1);
+    return k * ld + c16 * 8;
+  }
+}
+
+// Epilogue of one wave's (WM*16) x (WN*16) accumulator tile through its private LDS scratch (see file header).
+template <int WM, int WN, int CW, int EPI>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[WM][WN], char* scr, const Gemm2Args& p, int m0, int n0,
+                                              int split, int lane) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  constexpr int CPR = CW / 4;         // 16-byte chunks per scratch row
+  constexpr int RPI = 64 / CPR;       // rows one wave-instruction covers on the way out
+  const unsigned half_cols = (unsigned)(p.N >> 1);
+  float* slab = p.splits > 1 ? p.slab + (long)split * p.M * p.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int jc = 0; jc < (WN * 16) / CW; ++jc) {
+      // accumulators (MFMA layout: row l15, columns 16*j + 4*lg..+3) -> scratch
+#pragma unroll
+      for (int jj = 0; jj < CW / 16; ++jj) {
+        const int c16 = jj * 4 + lg;
+        *(f32x4*)(scr + l15 * (CW * 4) + ((c16 ^ (l15 & (CPR - 1))) << 4)) = acc[i][jc * (CW / 16) + jj];
+        acc[i][jc * (CW / 16) + jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      // scratch -> row-major: lane owns 4 consecutive columns of one row, CPR lanes cover a whole row segment
+#pragma unroll
+      for (int rr = 0; rr < 16 / RPI; ++rr) {
+        const int row = rr * RPI + lane / CPR, c16 = lane % CPR;
+        f32x4 v = *(const f32x4*)(scr + row * (CW * 4) + ((c16 ^ (row & (CPR - 1))) << 4));
+        const int m = m0 + i * 16 + row, n = n0 + jc * CW + c16 * 4;
+        if (slab) {
+          *(f32x4*)(slab + (long)m * p.N + n) = v;
+          continue;
+        }
+        long orow = m;
+        if (p.rpb > 0) {
+          const int b = m / p.rpb;
+          orow = (long)b * p.orb + (m - b * p.rpb) + p.roff;
+        }
+        v *= p.alpha;
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (EPI == 1) {
+          if (p.aux_out) {
+            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *(u32x2*)(p.aux_out + orow * p.ldaux + n) = pk;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (EPI == 2) {
+          bf16x4 u = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
+        }
+        if (p.drop.thr) {
+          float k0, k1, k2, k3;
+          drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n, k0, k1);
+          drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n + 2, k2, k3);
+          v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+        }
+        if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldres + n);
+        if (p.c_dtype == VIT_BF16) {
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(p.C + (orow * p.ldc + n) * 2) = pk;
+        } else {
+          *(f32x4*)(p.C + (orow * p.ldc + n) * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+// EPI: 0 = alpha/bias/dropout/residual/row-map (runtime flags), 1 = + erf-GELU (+ pre-activation save), 2 = * gelu'(aux)
+template <int BM, int BN, int BK, int NSTAGE, int A_T, int B_T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(Gemm2Args p) {
+  constexpr int NW = 8;
+  constexpr int WAVES_N = (BN == 256) ? 4 : 2, WAVES_M = NW / WAVES_N;
+  constexpr int WM = BM / WAVES_M / 16, WN = BN / WAVES_N / 16;
+  constexpr int KS = BK / 32;  // MFMA k-steps per K-tile
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int GA = A_BYTES / 8192, GB = B_BYTES / 8192, G = GA + GB;  // LDS-DMA instructions per thread per K-tile
+  constexpr int RING = NSTAGE * STAGE;
+  constexpr int SCR = (160 * 1024 - RING) / NW;        // epilogue scratch per wave: 4 KiB or 2 KiB
+  constexpr int CW = SCR / 64;                          // columns per epilogue chunk (16 rows x CW f32): 64 or 32
+  static_assert(SCR == 4096 || SCR == 2048, "ring + epilogue scratch must fill the 160 KiB LDS");
+  static_assert((WN * 16) % CW == 0, "wave tile width must be a multiple of the epilogue chunk");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int split = blockIdx.y;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin) / BK;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bx = blockIdx.x, nblk = p.nblk;
+  const int my_tiles = (ntile - bx + nblk - 1) / nblk;
+  const int total_it = my_tiles * nk;
+
+  int offA[GA], offB[GB];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK>(i, wave, lane, (int)p.lda);
+#pragma unroll
+  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK>(i, wave, lane, (int)p.ldb);
+
+  // tile index of this block's j-th tile: XCD-aware remap inside each round of nblk concurrently running tiles
+  auto tile_coords = [&](int j, int& tm, int& tn) {
+    const int round0 = j * nblk;
+    const int n_here = min(nblk, ntile - round0);
+    const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
+    const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int t = round0 + pos;
+    tm = t / p.tiles_n;
+    tn = t - tm * p.tiles_n;
+  };
+
+  auto issue = [&](int it) {
+    const int j = it / nk, kt = it - j * nk;
+    int tm, tn;
+    tile_coords(j, tm, tn);
+    const int k0 = k_begin + kt * BK;
+    const char* ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
+    const char* bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
+    char* st = smem + (it % NSTAGE) * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * 8192), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * 8192), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int tr_f = (tq | ((lg & 1) << 2)) << 2;
+  int kc_off[KS];  // K-contiguous image: byte offset of (row l15 of a 16-row block, k-step s)
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    kc_off[s] = (BK == 64) ? l15 * 128 + (((s * 4 + lg) ^ (l15 >> 1)) << 4) : l15 * 64 + ((lg ^ ((-(l15 >> 2)) & 3)) << 4);
+  auto read_frag = [&](const char* img, int trans, int rb_bytes, int base16, int s) -> bf16x8 {
+    if (!trans) {
+      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off[s]);
+    } else {
+      const char* pa = img + (s * 32 + lg * 8 + tq) * rb_bytes + ((((base16 >> 2) + tp) ^ tr_f) << 3);
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * rb_bytes));
+      return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int pre = 0; pre < NSTAGE - 1; ++pre)
+    if (pre < total_it) issue(pre);
+
+  char* scr = smem + RING + wave * SCR;  // this wave's epilogue scratch: [16 rows][CW f32], 16-B chunks XOR row
+  int kt = 0, jt = 0;
+  for (int it = 0; it < total_it; ++it) {
+    if (it + NSTAGE - 2 < total_it) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * G) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (it + NSTAGE - 1 < total_it) issue(it + NSTAGE - 1);
+
+    const char* As = smem + (it % NSTAGE) * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = read_frag(As, A_T, BM * 2, (wm * WM + i) * 16, s);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bf[j] = read_frag(Bs, B_T, BN * 2, (wn * WN + j) * 16, s);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+
+    if (++kt == nk) {
+      kt = 0;
+      int tm, tn;
+      tile_coords(jt, tm, tn);
+      ++jt;
+      tile_epilogue<WM, WN, CW, EPI>(acc, scr, p, tm * BM + wm * WM * 16, tn * BN + wn * WN * 16, split, lane);
+    }
+  }
+}
+
+// defined in gemm.hip / api.hip
+int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, int splits, float alpha, int accumulate,
+                         hipStream_t st);
+void* ctx_workspace(vit_handle h, size_t* bytes);
+
+template <int BM, int BN, int BK, int NSTAGE, int AT, int BT, int EPI>
+static int launch_one(const Gemm2Args& a, dim3 grid, hipStream_t st) {
+  constexpr int smem = 160 * 1024;
+  static bool attr_done = false;
+  auto fn = gemm2_kernel<BM, BN, BK, NSTAGE, AT, BT, EPI>;
+  if (!attr_done) {
+    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(512), smem, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+// instantiated combinations: plain epilogue for all four layouts; GELU only for Y = X W^T; dGELU only for dX = dY W
+template <int BM, int BN, int BK, int NSTAGE>
+static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
+  if (epi == 1) return launch_one<BM, BN, BK, NSTAGE, 0, 0, 1>(a, grid, st);
+  if (epi == 2) return launch_one<BM, BN, BK, NSTAGE, 0, 1, 2>(a, grid, st);
+  if (!at && !bt) return launch_one<BM, BN, BK, NSTAGE, 0, 0, 0>(a, grid, st);
+  if (!at && bt) return launch_one<BM, BN, BK, NSTAGE, 0, 1, 0>(a, grid, st);
+  if (at && !bt) return launch_one<BM, BN, BK, NSTAGE, 1, 0, 0>(a, grid, st);
+  return launch_one<BM, BN, BK, NSTAGE, 1, 1, 0>(a, grid, st);
+}
+
+// ------------------------------------------------------------------------------------------------ staggered variant
+// 256x256 tile, BK = 32, 4-stage ring, 3 K-tiles in flight.  The two wave halves (waves 0-3 / 4-7: partners on the
+// same SIMDs) run the K loop half a K-tile out of phase: in every phase one half is in its MFMA role (32 MFMAs per
+// wave on fragments it read in the previous phase) while the other is in its LOAD role (issue its share of the DMA for
+// K-tile t+3, read the fragments of K-tile t from the LDS).  One barrier per phase; all DMA waits sit at the end of odd
+// phases ("my parts of K-tile (ph+1)/2 have landed"), so a tile is complete one barrier before its first reader.
+template <int A_T, int B_T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
+  constexpr int BM = 256, BN = 256, BK = 32, NST = 4, S = 3, NW = 8;
+  constexpr int WM = 8, WN = 4;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int GA = A_BYTES / 8192, GB = B_BYTES / 8192, G = GA + GB;  // 4 DMA instructions per wave per K-tile
+  constexpr int RING = NST * STAGE, SCR = (160 * 1024 - RING) / NW, CW = SCR / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int split = blockIdx.y;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin) / BK;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bx = blockIdx.x, nblk = p.nblk;
+  const int my_tiles = (ntile - bx + nblk - 1) / nblk;
+  const int T = my_tiles * nk;
+
+  int offA[GA], offB[GB];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK>(i, wave, lane, (int)p.lda);
+#pragma unroll
+  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK>(i, wave, lane, (int)p.ldb);
+
+  auto tile_coords = [&](int j, int& tm, int& tn) {
+    const int round0 = j * nblk;
+    const int n_here = min(nblk, ntile - round0);
+    const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
+    const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    const int t = round0 + pos;
+    tm = t / p.tiles_n;
+    tn = t - tm * p.tiles_n;
+  };
+  auto issue = [&](int it) {
+    const int j = it / nk, kt = it - j * nk;
+    int tm, tn;
+    tile_coords(j, tm, tn);
+    const int k0 = k_begin + kt * BK;
+    const char* ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
+    const char* bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
+    char* st = smem + (it % NST) * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * 8192), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * 8192), 16, 0, 0);
+  };
+
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int tr_f = (tq | ((lg & 1) << 2)) << 2;
+  const int kc_off = l15 * 64 + ((lg ^ ((-(l15 >> 2)) & 3)) << 4);
+  auto read_frag = [&](const char* img, int trans, int rb_bytes, int base16) -> bf16x8 {
+    if (!trans) {
+      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off);
+    } else {
+      const char* pa = img + (lg * 8 + tq) * rb_bytes + ((((base16 >> 2) + tp) ^ tr_f) << 3);
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * rb_bytes));
+      return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[WM], bf[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < WN; ++j) bf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+
+#pragma unroll
+  for (int pre = 0; pre < S; ++pre)
+    if (pre < T) issue(pre);
+  if (S - 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * G) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  char* scr = smem + RING + wave * SCR;
+  int ktM = 0, jtM = 0;
+  for (int ph = 0; ph <= 2 * T; ++ph) {
+    if ((ph & 1) == grp) {
+      // ---- LOAD role: K-tile t
+      const int t = (ph - grp) >> 1;
+      if (t < T) {
+        if (t + S < T) issue(t + S);
+        const char* As = smem + (t % NST) * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = read_frag(As, A_T, BM * 2, (wm * WM + i) * 16);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = read_frag(Bs, B_T, BN * 2, (wn * WN + j) * 16);
+      }
+    } else {
+      // ---- MFMA role: K-tile t (fragments were read in the previous phase)
+      const int t = (ph - 1 - grp) >> 1;
+      if (t >= 0 && t < T) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (++ktM == nk) {
+          ktM = 0;
+          int tm, tn;
+          tile_coords(jtM, tm, tn);
+          ++jtM;
+          tile_epilogue<WM, WN, CW, EPI>(acc, scr, p, tm * BM + wm * WM * 16, tn * BN + wn * WN * 16, split, lane);
+        }
+      }
+    }
+    if (ph & 1) {
+      const int tw = (ph + 1) >> 1;  // my parts of this K-tile must have landed before the barrier
+      if (tw < T) {
+        if (tw + S - 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <int AT, int BT, int EPI>
+static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
+  constexpr int smem = 160 * 1024;
+  static bool attr_done = false;
+  auto fn = gemm3_kernel<AT, BT, EPI>;
+  if (!attr_done) {
+    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(512), smem, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
+  if (epi == 1) return launch_stag<0, 0, 1>(a, grid, st);
+  if (epi == 2) return launch_stag<0, 1, 2>(a, grid, st);
+  if (!at && !bt) return launch_stag<0, 0, 0>(a, grid, st);
+  if (!at && bt) return launch_stag<0, 1, 0>(a, grid, st);
+  if (at && !bt) return launch_stag<1, 0, 0>(a, grid, st);
+  return launch_stag<1, 1, 0>(a, grid, st);
+}
+
+int g_gemm2_mode = -1;  // -1: read VIT_GEMM2 from the environment on first use
+
+// returns 1 if handled (rc in *rc), 0 if the shape is not eligible
+int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* rc) {
+  if (g_gemm2_mode < 0) {
+    const char* e = getenv("VIT_GEMM2");
+    g_gemm2_mode = e ? atoi(e) : 1;
+  }
+  // 0 = off; 1 = automatic; 2 = 256x256 BK64 x2 stages; 3 = 256x128 BK64 x3 stages; 4 = 256x256 BK32 x4 stages;
+  // 5 = 256x256 BK32 x4 stages with the two wave halves staggered (LOAD role || MFMA role)
+  const int mode = g_gemm2_mode;
+  if (mode == 0) return 0;
+  if (d->M % 256 || d->N % 128 || d->K % 64) return 0;
+  if (d->lda * 256 >= (1L << 30) || d->ldb * 256 >= (1L << 30)) return 0;  // int offsets inside a tile
+  int epi = 0;
+  if (d->act == VIT_ACT_GELU) {
+    if (d->a_trans || d->b_trans) return 0;
+    epi = 1;
+  } else if (d->act == VIT_ACT_DGELU) {
+    if (d->a_trans || !d->b_trans) return 0;
+    epi = 2;
+  }
+  // automatic choice, from tools/gemm_bench.py on the ViT-B shapes (MI355X): the 256x256xBK64 LDS-DMA geometry wins for
+  // Y = X W^T and dW = dY^T X with N >= 2304 (QKV and FC1 forward +35 %, FC2's dW +10 %); the register-staged 128x128
+  // core (two independent workgroups per CU) wins or ties everywhere else, notably for dX = dY W.
+  int cfg = mode;
+  if (mode == 1) {
+    if (d->a_trans == d->b_trans && d->N >= 2304 && d->N % 256 == 0) cfg = 2;
+    else return 0;
+  }
+  if (d->N % 256) cfg = 3;
+  const int bn = (cfg == 3) ? 128 : 256;
+  const int slots = 256;
+
+  Gemm2Args a;
+  a.A = (const char*)d->A; a.B = (const char*)d->B; a.C = (char*)d->C;
+  a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.tiles_m = d->M / 256; a.tiles_n = d->N / bn;
+  const int ntile = a.tiles_m * a.tiles_n;
+  const int ktiles = d->K / 64;
+  int splits = d->split_k;
+  if (splits < 0) {
+    splits = 1;
+    if (ntile < slots) splits = std::min(std::max(1, slots / ntile), std::max(1, ktiles / 8));
+  }
+  if (splits < 1) splits = 1;
+  if (splits > ktiles) splits = ktiles;
+  const int kps = cdiv(ktiles, splits) * 64;
+  splits = cdiv(d->K, kps);
+  a.splits = splits; a.k_per_split = kps;
+  a.slab = nullptr;
+  if (splits > 1) {
+    if (!(d->c_dtype == VIT_F32 && !d->bias && d->act == VIT_ACT_NONE && d->dropout_p == 0.f && !d->residual &&
+          d->rows_per_batch == 0)) return 0;
+    size_t wsb = 0;
+    void* ws = ctx_workspace(h, &wsb);
+    const size_t need = (size_t)splits * d->M * d->N * 4;
+    if (!ws || wsb < need) {
+      set_error("vit_gemm: split-K needs %zu workspace bytes, have %zu", need, wsb);
+      *rc = VIT_ERR_WORKSPACE;
+      return 1;
+    }
+    a.slab = (float*)ws;
+  }
+  a.nblk = std::min(ntile, slots);
+  a.bias = d->bias;
+  a.aux_in = (const short*)d->aux_in; a.aux_out = (short*)d->aux_out; a.ldaux = d->ldaux;
+  a.residual = d->residual; a.ldres = d->ldres;
+  if (d->accumulate && splits == 1) {
+    if (!(d->c_dtype == VIT_F32 && !d->residual && d->rows_per_batch == 0)) return 0;
+    a.residual = (const float*)d->C; a.ldres = d->ldc;
+  }
+  a.alpha = d->alpha;
+  a.act = d->act; a.c_dtype = d->c_dtype;
+  a.drop = make_drop(d->dropout_p, d->seed, d->site);
+  a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
+
+  dim3 grid(a.nblk, splits);
+  int r;
+  if (cfg == 2) r = launch_cfg<256, 256, 64, 2>(a, d->a_trans, d->b_trans, epi, grid, st);
+  else if (cfg == 3) r = launch_cfg<256, 128, 64, 3>(a, d->a_trans, d->b_trans, epi, grid, st);
+  else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi, grid, st);
+  else r = launch_cfg<256, 256, 32, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
+  if (r == VIT_OK && splits > 1)
+    r = launch_splitk_reduce(a.slab, (float*)d->C, (long)d->ldc, d->M, d->N, splits, d->alpha, d->accumulate, st);
+  *rc = r;
+  return 1;
+}
+
+}  // namespace vit

@@ -67,10 +67,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
     d.split_k = split_k
     d.accumulate = int(accumulate)
     if split_k != 0 and split_k != 1:
-        if split_k < 0:  # same rule as gemm_launch's automatic choice
+        if split_k < 0:  # upper bound over the automatic choices of both GEMM cores (gemm.hip / gemm2.hip)
             tiles = -(-M // 128) * -(-N // 128)
             ktiles = -(-K // 64)
             split_k = min(max(1, 512 // tiles), max(1, ktiles // 4)) if tiles < 256 else 1
+            t2 = max(1, (M // 256) * max(1, N // 256))
+            split_k = max(split_k, min(max(1, 256 // t2), max(1, ktiles // 8)) + 1)
         h.ensure_workspace(split_k * M * N * 4)
         split_k = d.split_k
     check(h.lib.vit_gemm(h.h, C.byref(d), _stream(a)), "vit_gemm")
