@@ -437,6 +437,450 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict
   for (int k = lane; k < T; k += 64) out[k] *= inv;
 }
 
+// ======================================================================================= resident kernels (T <= 256)
+// When a (batch, head)'s whole K and V (or Q and dO) fit the LDS -- T <= 256: every config of BASELINE.json's bench
+// line -- one workgroup owns the (batch, head): the tiles are staged ONCE, there is a single barrier, and every wave
+// then runs its key loop without any synchronisation.  Each wave owns RQ = 2 sixteen-row tiles and feeds both from
+// every K / V fragment it reads, which halves the LDS read traffic per MFMA (the 4-wave tiled kernels above were
+// LDS-read and barrier bound at ~135 TFLOP/s).
+// Stage two [T, dh] matrices (all their 64-row tiles) at once: every global load of a thread is issued before its first
+// LDS store, so a workgroup pays ONE memory latency for its whole working set (a load->store loop paid ten).
+template <int DH>
+__device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, long lda, char* imgB, const short* gb,
+                                                long ldb, int T, int dh, int ntl, int tid, int nthr) {
+  constexpr int CPR = DH / 8, MAXI = 8;
+  const int total = ntl * RT * CPR;
+  for (int base = 0; base < total; base += MAXI * nthr) {
+    i32x4 va[MAXI], vb[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int q = base + tid + i * nthr;
+      const int r = q / CPR, c = q % CPR;
+      va[i] = vb[i] = (i32x4){0, 0, 0, 0};
+      if (q < total && r < T && c * 8 < dh) {
+        va[i] = *(const i32x4*)(ga + (long)r * lda + c * 8);
+        vb[i] = *(const i32x4*)(gb + (long)r * ldb + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int q = base + tid + i * nthr;
+      if (q < total) {
+        const int r = q / CPR, c = q % CPR;
+        const int off = (r >> 6) * (RT * DH * 2) + tile_off<DH>(r & 63, c);
+        *(i32x4*)(imgA + off) = va[i];
+        *(i32x4*)(imgB + off) = vb[i];
+      }
+    }
+  }
+}
+
+template <int DH, int RQ>
+__global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = RT * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const long ld = 3L * p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  char* Kimg = smem;
+  char* Vimg = smem + ntl * TILE;
+  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
+  __syncthreads();
+  const int q00 = wave * RQ * 16;
+  if (q00 >= T) return;  // no barrier after this point
+
+  bf16x8 qf[RQ][DH / 32];
+  float m[RQ], l[RQ];
+  f32x4 ot[RQ][DH / 16];
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
+    m[rq] = -INFINITY;
+    l[rq] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) ot[rq][i] = zero4();
+  }
+  const float c = p.scale * LOG2E;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+
+  for (int kt = 0; kt < ntl; ++kt) {
+    const int kb = kt * RT;
+    const char* Kt = Kimg + kt * TILE;
+    const char* Vt = Vimg + kt * TILE;
+    f32x4 st[RQ][4];
+    float mx[RQ];
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) mx[rq] = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j * 16 < T) {
+        f32x4 a[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) a[rq] = zero4();
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          const bf16x8 kf = frag_rows<DH>(Kt, j * 16, s, l15, lg);
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) a[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][s], a[rq], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kb + j * 16 + lg * 4 + r;
+            a[rq][r] = key < T ? a[rq][r] * c : -INFINITY;
+            mx[rq] = fmaxf(mx[rq], a[rq][r]);
+          }
+          st[rq][j] = a[rq];
+        }
+      } else {
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) st[rq][j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+      const float mn = fmaxf(m[rq], grp4_max(mx[rq]));
+      const float alpha = fast_exp2(m[rq] - mn);
+      m[rq] = mn;
+      float ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[rq][j][r] = fast_exp2(st[rq][j][r] - mn);
+          ls += st[rq][j][r];
+        }
+      l[rq] = l[rq] * alpha + ls;
+#pragma unroll
+      for (int i = 0; i < DH / 16; ++i) ot[rq][i] *= alpha;
+      if (p.drop.thr) {
+        const unsigned long long drow = (unsigned long long)bh * T + (q00 + rq * 16 + l15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned key = kb + j * 16 + lg * 4;
+          float k0, k1, k2, k3;
+          drop_pair(p.drop, drow, half_cols, key, k0, k1);
+          drop_pair(p.drop, drow, half_cols, key + 2, k2, k3);
+          st[rq][j][0] *= k0; st[rq][j][1] *= k1; st[rq][j][2] *= k2; st[rq][j][3] *= k3;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb + u * 32 < T) {
+        bf16x8 pf[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) pf[rq] = pack8(st[rq][2 * u], st[rq][2 * u + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          const bf16x8 vf = frag_cols<DH>(Vt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq)
+            ot[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rq], ot[rq][dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    const float lt = grp4_sum(l[rq]);
+    const int q = q00 + rq * 16 + l15;
+    if (q < T) {
+      const float inv = 1.0f / lt;
+      short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const int d = dt * 16 + lg * 4;
+        if (d < dh) {
+          const f32x4 v = ot[rq][dt] * inv;
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(o + d) = pk;
+        }
+      }
+      if (lg == 0) p.lse[(long)bh * T + q] = (m[rq] + log2f(lt)) * LN2;
+    }
+  }
+}
+
+template <int DH, int RQ>
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = RT * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  const short* ob = p.ctx + (long)b * T * ldc + h * dh;
+  char* Kimg = smem;
+  char* Vimg = smem + ntl * TILE;
+  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
+  __syncthreads();
+  const int q00 = wave * RQ * 16;
+  if (q00 >= T) return;
+
+  bf16x8 qf[RQ][DH / 32], dof[RQ][DH / 32];
+  float lse2[RQ], del[RQ];
+  f32x4 dqt[RQ][DH / 16];
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    const int q = q00 + rq * 16 + l15;
+    load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
+    load_own<DH>(dof[rq], dob, ldc, q00 + rq * 16, T, dh, l15, lg);
+    lse2[rq] = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
+    float d_ = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 32; ++s) {
+      const int col = s * 32 + lg * 8;
+      if (q < T && col < dh) {
+        const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d_ += bf2f(o[e]) * bf2f(dof[rq][s][e]);
+      }
+    }
+    d_ = grp4_sum(d_);
+    if (q < T && lg == 0) p.delta[(long)bh * T + q] = d_;
+    del[rq] = d_;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) dqt[rq][i] = zero4();
+  }
+  const float c = p.scale * LOG2E;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+
+  for (int kt = 0; kt < ntl; ++kt) {
+    const int kb = kt * RT;
+    const char* Kt = Kimg + kt * TILE;
+    const char* Vt = Vimg + kt * TILE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (kb + u * 32 >= T) continue;
+      f32x4 ds[RQ][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * u + jj;
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) ds[rq][jj] = zero4();
+        if (kb + j * 16 < T) {
+          f32x4 s_[RQ], dp[RQ];
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
+#pragma unroll
+          for (int s = 0; s < DH / 32; ++s) {
+            const bf16x8 kf = frag_rows<DH>(Kt, j * 16, s, l15, lg);
+            const bf16x8 vf = frag_rows<DH>(Vt, j * 16, s, l15, lg);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][s], s_[rq], 0, 0, 0);
+              dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[rq][s], dp[rq], 0, 0, 0);
+            }
+          }
+          const unsigned key0 = kb + j * 16 + lg * 4;
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) {
+            float k[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop.thr) {
+              const unsigned long long drow = (unsigned long long)bh * T + (q00 + rq * 16 + l15);
+              drop_pair(p.drop, drow, half_cols, key0, k[0], k[1]);
+              drop_pair(p.drop, drow, half_cols, key0 + 2, k[2], k[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = ((int)key0 + r < T) ? fast_exp2(s_[rq][r] * c - lse2[rq]) : 0.f;
+              ds[rq][jj][r] = pr * (dp[rq][r] * k[r] - del[rq]);
+            }
+          }
+        }
+      }
+      bf16x8 df[RQ];
+#pragma unroll
+      for (int rq = 0; rq < RQ; ++rq) df[rq] = pack8(ds[rq][0], ds[rq][1]);
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const bf16x8 ktf = frag_cols<DH>(Kt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq)
+          dqt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, df[rq], dqt[rq][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    const int q = q00 + rq * 16 + l15;
+    if (q < T) {
+      short* o = p.dqkv + ((long)b * T + q) * ld + h * dh;
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const int d = dt * 16 + lg * 4;
+        if (d < dh) {
+          const f32x4 v = dqt[rq][dt] * p.scale;
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(o + d) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <int DH, int RQ>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = RT * DH * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  char* Qimg = smem;
+  char* Oimg = smem + ntl * TILE;
+  float* lse_s = (float*)(smem + 2 * ntl * TILE);
+  float* del_s = lse_s + ntl * RT;
+  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, ntl, tid, blockDim.x);
+  for (int i = tid; i < ntl * RT; i += blockDim.x) {
+    lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
+    del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
+  }
+  __syncthreads();
+  const int k00 = wave * RQ * 16;
+  if (k00 >= T) return;
+
+  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
+  f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, dh, l15, lg);
+    load_own<DH>(vf[rq], vb, ld, k00 + rq * 16, T, dh, l15, lg);
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) dkt[rq][i] = dvt[rq][i] = zero4();
+  }
+  const float c = p.scale * LOG2E;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+  const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
+
+  for (int qt = 0; qt < ntl; ++qt) {
+    const int qb0 = qt * RT;
+    const char* Qt = Qimg + qt * TILE;
+    const char* Ot = Oimg + qt * TILE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (qb0 + u * 32 >= T) continue;
+      u32x2 pdh[RQ][2], dsh[RQ][2];  // P*mask and dS, packed to bf16 as soon as they exist (register pressure)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * u + jj;
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
+        if (qb0 + j * 16 < T) {
+          f32x4 s_[RQ], dp[RQ];
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
+#pragma unroll
+          for (int s = 0; s < DH / 32; ++s) {
+            const bf16x8 qfr = frag_rows<DH>(Qt, j * 16, s, l15, lg);
+            const bf16x8 ofr = frag_rows<DH>(Ot, j * 16, s, l15, lg);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
+              dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
+            }
+          }
+          const f32x4 l4 = *(const f32x4*)(lse_s + qb0 + j * 16 + lg * 4);
+          const f32x4 d4 = *(const f32x4*)(del_s + qb0 + j * 16 + lg * 4);
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) {
+            const unsigned key = k00 + rq * 16 + l15;
+            float pdv[4], dsv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
+              float mk = 1.f;
+              if (p.drop.thr) {
+                // pair index = (bh*T + q) * half_cols + key/2, split into a wave-uniform 64-bit base and a small
+                // per-lane 32-bit part (the straightforward 64-bit form cost ~70 VGPRs here)
+                const unsigned idx32 = (unsigned)(qb0 + j * 16 + lg * 4 + r) * half_cols + (key >> 1);
+                const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
+                const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+                mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
+              }
+              pdv[r] = pr * mk;
+              dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+            }
+            pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
+            dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+          }
+        }
+      }
+      bf16x8 pf[RQ], df[RQ];
+#pragma unroll
+      for (int rq = 0; rq < RQ; ++rq) {
+        pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
+        df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
+      }
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const bf16x8 otf = frag_cols<DH>(Ot, u * 32, u * 32 + 16, dt * 16, l15, lg);
+        const bf16x8 qtf = frag_cols<DH>(Qt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
+          dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    const int key = k00 + rq * 16 + l15;
+    if (key < T) {
+      short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * dh + h * dh;
+      short* ov = ok + p.H * dh;
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const int d = dt * 16 + lg * 4;
+        if (d < dh) {
+          const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
+          u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+          u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(ok + d) = pk;
+          *(u32x2*)(ov + d) = pv;
+        }
+      }
+    }
+  }
+}
+
+constexpr int RES_MAX_T = 256, RES_MAX_DH = 64, RES_RQ = 2;
+
+template <typename F>
+static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
+  // dynamic LDS above 64 KiB needs the attribute; set it to the CU's 160 KiB once per kernel
+  static bool done = false;
+  if (!done) {
+    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  const int nq = cdiv(a.T, 16), nw = cdiv(nq, RES_RQ);
+  hipLaunchKernelGGL(fn, dim3(a.B * a.H), dim3(nw * 64), smem, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+#define DISPATCH_RES(KERNEL, a, smem_expr, st, rc)                                          \
+  do {                                                                                      \
+    if (a.dh <= 32) { constexpr int DH_ = 32; rc = launch_res(KERNEL<32, RES_RQ>, a, smem_expr, st); }        \
+    else { constexpr int DH_ = 64; rc = launch_res(KERNEL<64, RES_RQ>, a, smem_expr, st); }                    \
+  } while (0)
+
 static int check_attn(const char* fn, int B, int H, int T, int dh, float p) {
   VIT_CHECK(B > 0 && H > 0 && T > 0 && dh > 0, VIT_ERR_ARG, "%s: B=%d H=%d T=%d dh=%d", fn, B, H, T, dh);
   VIT_CHECK((dh % 8) == 0 && dh <= 128, VIT_ERR_UNSUPPORTED, "%s: head dim %d (need a multiple of 8, <= 128)", fn, dh);
@@ -466,6 +910,11 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
   a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
+  if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
+    const size_t ntl = cdiv(T, RT);
+    DISPATCH_RES(attn_fwd_res_kernel, a, (2 * ntl * RT * DH_ * 2), (hipStream_t)stream, rc);
+    return rc;
+  }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
   DISPATCH_DH(attn_fwd_kernel, grid, (hipStream_t)stream, a);
   VIT_LAUNCH_CHECK();
@@ -485,6 +934,13 @@ int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
+  if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
+    const size_t ntl = cdiv(T, RT);
+    DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * ntl * RT * DH_ * 2), st, rc);
+    if (rc != VIT_OK) return rc;
+    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * ntl * RT * DH_ * 2 + 2 * ntl * RT * 4), st, rc);
+    return rc;
+  }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
   DISPATCH_DH(attn_bwd_dq_kernel, grid, st, a);
   VIT_LAUNCH_CHECK();

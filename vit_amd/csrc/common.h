@@ -130,6 +130,17 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- reductions across the 4 lane groups lane>>4 (all 64 lanes end with the result)
+__device__ __forceinline__ float grp4_max(float x) {
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+__device__ __forceinline__ float grp4_sum(float x) {
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32
+
 // ---- raw buffer resources: hardware bounds check, out-of-range lanes read 0 --------------------------
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned long long bytes) {
   unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
