@@ -45,7 +45,10 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
 /* Process-wide tuning / diagnostics knobs (never change results beyond rounding order):
  *   "gemm_core": 0 = generic 128x128 core only, 1 = automatic (default); on tile-aligned problems 2 / 3 / 4 force the
  *                LDS-DMA core's 256x256xBK64 (2 stages) / 256x128xBK64 (3 stages) / 256x256xBK32 (4 stages) geometry,
- *                5 the staggered 256x256xBK32 variant (wave halves alternate LOAD and MFMA roles).
+ *                5 the staggered 256x256xBK32 variant (wave halves alternate LOAD and MFMA roles), 6 the 4-wave
+ *                256x128xBK32 (3 stages) geometry with two workgroups per CU.
+ *   "gemm_debug": timing diagnostics for the LDS-DMA core (1 = skip operand DMA after the prologue, 2 = skip MFMAs);
+ *                results are meaningless while it is non-zero.
  *                Returns VIT_ERR_ARG for an unknown name. */
 int vit_set_option(const char* name, int value);
 
@@ -108,6 +111,14 @@ int vit_layernorm_fwd(vit_handle h, const float* x, const float* gamma, const fl
 int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
                       const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
                       float* dbeta, int rows, int D, vit_stream stream);
+
+/* Same, fused with what always follows it in this path: also writes dyn (bf16 [rows, D]) = dropout_mask(seed, site) *
+ * dx -- the gradient wrt the output of the Linear under "dropout(Linear(.)) + residual" -- and dbias (f32 [D]) = its
+ * column sums (that Linear's bias gradient): one pass instead of vit_dropout_bwd_cast + vit_colsum re-reading dx. */
+int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                            const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                            float* dbeta, int rows, int D, void* dyn, float* dbias, float dropout_p, uint64_t seed,
+                            uint64_t site, vit_stream stream);
 
 /* ------------------------------------------------------------------------------------------- Attention
  * softmax(Q K^T * scale) -> dropout -> * V, per (batch, head); flash-style (scores never reach HBM).

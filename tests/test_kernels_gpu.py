@@ -355,7 +355,7 @@ def test_sqnorm_adamw(dev):
 ALIGNED = [(256, 128, 64), (512, 256, 128), (1024, 768, 768), (2304, 768, 256), (768, 3072, 768), (1792, 2304, 768)]
 
 
-@pytest.mark.parametrize("core", [2, 3, 4, 5])
+@pytest.mark.parametrize("core", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K", ALIGNED)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
 def test_gemm2_layouts(dev, core, M, N, K, layout):
@@ -379,7 +379,7 @@ def test_gemm2_layouts(dev, core, M, N, K, layout):
     assert rel(sk, ref) < 2e-5
 
 
-@pytest.mark.parametrize("core", [0, 2, 3, 4, 5])
+@pytest.mark.parametrize("core", [0, 2, 3, 4, 5, 6])
 def test_gemm2_epilogues_match_generic_core(dev, core):
     """Every fused epilogue on a tile-aligned problem, each core against the torch reference (and so against each other)."""
     import vit_amd.functional as vf
@@ -437,3 +437,23 @@ def test_gemm2_many_tiles_persistent(dev):
     a = bf(randn((M, K), dev, 14))
     o = vf.gemm(a, b, M=M, N=N, K=K, out_dtype=torch.float32)
     assert rel(o, a.float() @ b.float().t()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,D", [(516, 32), (1000, 768), (77, 1024)])
+def test_layernorm_bwd_fused(dev, rows, D):
+    """The fused form must equal layernorm_bwd -> dropout_bwd_cast -> colsum on the same inputs (bit for bit on dyn)."""
+    import vit_amd.functional as vf
+
+    x = randn((rows, D), dev, 80) * 2 + 0.3
+    g, b = randn((D,), dev, 81) * 0.1 + 1, randn((D,), dev, 82) * 0.1
+    _, mean, rstd = vf.layernorm_fwd(x, g, b, 1e-12, out_dtype=torch.float32)
+    dy, dres = bf(randn((rows, D), dev, 83)), randn((rows, D), dev, 84)
+    for drop in ((0.0, 0, 0), (0.1, 321, 9)):
+        dx0, dg0, db0 = vf.layernorm_bwd(dy, x, g, mean, rstd, dres=dres)
+        dyn0 = vf.dropout_bwd_cast(dx0, drop)
+        dbias0 = vf.colsum(dyn0)
+        E = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=dev)
+        dx1, dg1, db1, dyn1, dbias1 = vf.layernorm_bwd_fused(dy, x, g, mean, rstd, dres, E(rows, D), E(D), E(D),
+                                                             E(rows, D, dt=torch.bfloat16), E(D), drop)
+        assert torch.equal(dx1, dx0) and torch.equal(dyn1, dyn0)
+        assert rel(dg1, dg0) < 1e-6 and rel(db1, db0) < 1e-6 and rel(dbias1, dbias0) < 1e-5

@@ -17,7 +17,7 @@ from vit_amd._cabi import ACT_DGELU, ACT_GELU
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--cores", default="0,2,4,5")
+    ap.add_argument("--cores", default="0,2,6")
     ap.add_argument("--M", type=int, default=50432)
     args = ap.parse_args()
     cores = [int(c) for c in args.cores.split(",")]

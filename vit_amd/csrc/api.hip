@@ -13,7 +13,7 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode;  // gemm2.hip
+extern int g_gemm2_mode, g_gemm2_debug;  // gemm2.hip
 
 static thread_local char g_err[512] = "";
 
@@ -66,8 +66,12 @@ int vit_destroy(vit_handle h) {
 int vit_set_option(const char* name, int value) {
   VIT_CHECK(name, VIT_ERR_ARG, "vit_set_option: null name");
   if (strcmp(name, "gemm_core") == 0) {
-    VIT_CHECK(value >= 0 && value <= 5, VIT_ERR_ARG, "vit_set_option: gemm_core must be 0..5");
+    VIT_CHECK(value >= 0 && value <= 6, VIT_ERR_ARG, "vit_set_option: gemm_core must be 0..6");
     vit::g_gemm2_mode = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "gemm_debug") == 0) {  // timing diagnostics of the LDS-DMA core; results are meaningless when set
+    vit::g_gemm2_debug = value;
     return VIT_OK;
   }
   vit::set_error("vit_set_option: unknown option '%s'", name);

@@ -153,6 +153,6 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // out[c] (+)= sum_{k < nblk} part[k * width + c]; columns [0, split) go to out0, [split, width) to out1 (- split).
 // 64 columns x 16 row groups per block, fixed summation order (deterministic).  Defined in elementwise.hip.
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
-                           hipStream_t st);
+                           hipStream_t st, int stride = 0 /* floats between partial rows; 0 = width */);
 
 }  // namespace vit

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restri
 }
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int width,
                                                                float* __restrict__ out0, int split,
-                                                               float* __restrict__ out1, int accumulate) {
+                                                               float* __restrict__ out1, int accumulate, int stride) {
   __shared__ float red[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   if (c < width) {
     int k = ty;
     for (; k + 16 < nblk; k += 32) {
-      a0 += part[(long)k * width + c];
-      a1 += part[(long)(k + 16) * width + c];
+      a0 += part[(long)k * stride + c];
+      a1 += part[(long)(k + 16) * stride + c];
     }
-    if (k < nblk) a0 += part[(long)k * width + c];
+    if (k < nblk) a0 += part[(long)k * stride + c];
   }
   red[ty][tx] = a0 + a1;
   __syncthreads();
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
 }
 
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
-                           hipStream_t st) {
+                           hipStream_t st, int stride) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(width, 64)), dim3(1024), 0, st, part, nblk, width, out0, split,
-                     out1, accumulate);
+                     out1, accumulate, stride ? stride : width);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

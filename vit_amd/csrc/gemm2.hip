@@ -44,26 +44,28 @@ struct Gemm2Args {
   int act, c_dtype;
   DropCfg drop;
   int rpb, orb, roff;
+  int debug;  // diagnostics only (vit_set_option "gemm_debug"): 1 = no DMA after the prologue, 2 = no MFMA
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
 
-// per-thread DMA source offset (elements) of round i for one operand image; destination = i*8192 + wave*1024 + lane*16
-template <int TRANS, int R, int BK>
+// per-thread DMA source offset (elements) of round i for one operand image (NW waves issue NW KiB per round);
+// destination = i*NW*1024 + wave*1024 + lane*16
+template <int TRANS, int R, int BK, int NW>
 __device__ __forceinline__ int dma_src_off(int i, int wave, int lane, int ld) {
   if (TRANS == 0) {
     if (BK == 64) {
-      const int row = i * 64 + wave * 8 + (lane >> 3);
+      const int row = i * (NW * 8) + wave * 8 + (lane >> 3);
       const int c = (lane & 7) ^ ((row >> 1) & 7);
       return row * ld + c * 8;
     } else {
-      const int row = i * 128 + wave * 16 + (lane >> 2);
+      const int row = i * (NW * 16) + wave * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
       return row * ld + c * 8;
     }
   } else {
     constexpr int RB = R * 2, LPR = RB / 16;
-    const int k = i * (8192 / RB) + wave * (1024 / RB) + lane / LPR;
+    const int k = i * (NW * 1024 / RB) + wave * (1024 / RB) + lane / LPR;
     const int c16 = (lane % LPR) ^ (tr_swz2(k) >> 1);
     return k * ld + c16 * 8;
   }
@@ -137,18 +139,21 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[WM][WN], char* scr, c
 }
 
 // EPI: 0 = alpha/bias/dropout/residual/row-map (runtime flags), 1 = + erf-GELU (+ pre-activation save), 2 = * gelu'(aux)
-template <int BM, int BN, int BK, int NSTAGE, int A_T, int B_T, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(Gemm2Args p) {
-  constexpr int NW = 8;
-  constexpr int WAVES_N = (BN == 256) ? 4 : 2, WAVES_M = NW / WAVES_N;
+// NW = 8: one 512-thread workgroup per CU (160 KiB LDS); NW = 4: two independent 256-thread workgroups per CU (80 KiB
+// each), so one workgroup's epilogue / DMA waits overlap the other's MFMAs.
+template <int BM, int BN, int BK, int NSTAGE, int NW, int A_T, int B_T, int EPI>
+__global__ __launch_bounds__(NW * 64, 2) void gemm2_kernel(Gemm2Args p) {
+  constexpr int WAVES_N = (NW == 8 && BN == 256) ? 4 : 2, WAVES_M = NW / WAVES_N;
+  constexpr int LDS_TOTAL = (NW == 8) ? 160 * 1024 : 80 * 1024;
+  constexpr int RND = NW * 1024;  // bytes one DMA round (one instruction per wave) moves
   constexpr int WM = BM / WAVES_M / 16, WN = BN / WAVES_N / 16;
   constexpr int KS = BK / 32;  // MFMA k-steps per K-tile
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int GA = A_BYTES / 8192, GB = B_BYTES / 8192, G = GA + GB;  // LDS-DMA instructions per thread per K-tile
+  constexpr int GA = A_BYTES / RND, GB = B_BYTES / RND, G = GA + GB;  // LDS-DMA instructions per thread per K-tile
   constexpr int RING = NSTAGE * STAGE;
-  constexpr int SCR = (160 * 1024 - RING) / NW;        // epilogue scratch per wave: 4 KiB or 2 KiB
+  constexpr int SCR = (LDS_TOTAL - RING) / NW;         // epilogue scratch per wave: 4 KiB or 2 KiB
   constexpr int CW = SCR / 64;                          // columns per epilogue chunk (16 rows x CW f32): 64 or 32
-  static_assert(SCR == 4096 || SCR == 2048, "ring + epilogue scratch must fill the 160 KiB LDS");
+  static_assert(SCR == 4096 || SCR == 2048, "ring + epilogue scratch must fill the workgroup's LDS share");
   static_assert((WN * 16) % CW == 0, "wave tile width must be a multiple of the epilogue chunk");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -167,19 +172,25 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(Gemm2Args p) {
 
   int offA[GA], offB[GB];
 #pragma unroll
-  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK>(i, wave, lane, (int)p.lda);
+  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK, NW>(i, wave, lane, (int)p.lda);
 #pragma unroll
-  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK>(i, wave, lane, (int)p.ldb);
+  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK, NW>(i, wave, lane, (int)p.ldb);
 
   // tile index of this block's j-th tile: XCD-aware remap inside each round of nblk concurrently running tiles
   auto tile_coords = [&](int j, int& tm, int& tn) {
     const int round0 = j * nblk;
     const int n_here = min(nblk, ntile - round0);
     const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
-    const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    if (p.debug & 4) pos = bx;            // diagnostics: no XCD remap
     const int t = round0 + pos;
-    tm = t / p.tiles_n;
-    tn = t - tm * p.tiles_n;
+    if (p.debug & 8) {                     // diagnostics: m fastest (neighbours share the B panel)
+      tn = t / p.tiles_m;
+      tm = t - tn * p.tiles_m;
+    } else {
+      tm = t / p.tiles_n;
+      tn = t - tm * p.tiles_n;
+    }
   };
 
   auto issue = [&](int it) {
@@ -192,10 +203,10 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(Gemm2Args p) {
     char* st = smem + (it % NSTAGE) * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * RND), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < GB; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * RND), 16, 0, 0);
   };
 
   // ---- fragment read offsets
@@ -235,10 +246,11 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(Gemm2Args p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (it + NSTAGE - 1 < total_it) issue(it + NSTAGE - 1);
+    if (it + NSTAGE - 1 < total_it && !(p.debug & 1)) issue(it + NSTAGE - 1);
 
     const char* As = smem + (it % NSTAGE) * STAGE;
     const char* Bs = As + A_BYTES;
+    if (!(p.debug & 2))
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       bf16x8 af[WM], bf[WN];
@@ -268,29 +280,29 @@ int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, in
                          hipStream_t st);
 void* ctx_workspace(vit_handle h, size_t* bytes);
 
-template <int BM, int BN, int BK, int NSTAGE, int AT, int BT, int EPI>
+template <int BM, int BN, int BK, int NSTAGE, int NW, int AT, int BT, int EPI>
 static int launch_one(const Gemm2Args& a, dim3 grid, hipStream_t st) {
-  constexpr int smem = 160 * 1024;
+  constexpr int smem = (NW == 8) ? 160 * 1024 : 80 * 1024;
   static bool attr_done = false;
-  auto fn = gemm2_kernel<BM, BN, BK, NSTAGE, AT, BT, EPI>;
+  auto fn = gemm2_kernel<BM, BN, BK, NSTAGE, NW, AT, BT, EPI>;
   if (!attr_done) {
     VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(512), smem, st, a);
+  hipLaunchKernelGGL(fn, grid, dim3(NW * 64), smem, st, a);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
 
 // instantiated combinations: plain epilogue for all four layouts; GELU only for Y = X W^T; dGELU only for dX = dY W
-template <int BM, int BN, int BK, int NSTAGE>
+template <int BM, int BN, int BK, int NSTAGE, int NW>
 static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
-  if (epi == 1) return launch_one<BM, BN, BK, NSTAGE, 0, 0, 1>(a, grid, st);
-  if (epi == 2) return launch_one<BM, BN, BK, NSTAGE, 0, 1, 2>(a, grid, st);
-  if (!at && !bt) return launch_one<BM, BN, BK, NSTAGE, 0, 0, 0>(a, grid, st);
-  if (!at && bt) return launch_one<BM, BN, BK, NSTAGE, 0, 1, 0>(a, grid, st);
-  if (at && !bt) return launch_one<BM, BN, BK, NSTAGE, 1, 0, 0>(a, grid, st);
-  return launch_one<BM, BN, BK, NSTAGE, 1, 1, 0>(a, grid, st);
+  if (epi == 1) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 0, 1>(a, grid, st);
+  if (epi == 2) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 1, 2>(a, grid, st);
+  if (!at && !bt) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 0, 0>(a, grid, st);
+  if (!at && bt) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 1, 0>(a, grid, st);
+  if (at && !bt) return launch_one<BM, BN, BK, NSTAGE, NW, 1, 0, 0>(a, grid, st);
+  return launch_one<BM, BN, BK, NSTAGE, NW, 1, 1, 0>(a, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------------ staggered variant
@@ -323,9 +335,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 
   int offA[GA], offB[GB];
 #pragma unroll
-  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK>(i, wave, lane, (int)p.lda);
+  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK, 8>(i, wave, lane, (int)p.lda);
 #pragma unroll
-  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK>(i, wave, lane, (int)p.ldb);
+  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK, 8>(i, wave, lane, (int)p.ldb);
 
   auto tile_coords = [&](int j, int& tm, int& tn) {
     const int round0 = j * nblk;
@@ -453,6 +465,7 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
 }
 
 int g_gemm2_mode = -1;  // -1: read VIT_GEMM2 from the environment on first use
+int g_gemm2_debug = 0;
 
 // returns 1 if handled (rc in *rc), 0 if the shape is not eligible
 int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* rc) {
@@ -461,7 +474,8 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     g_gemm2_mode = e ? atoi(e) : 1;
   }
   // 0 = off; 1 = automatic; 2 = 256x256 BK64 x2 stages; 3 = 256x128 BK64 x3 stages; 4 = 256x256 BK32 x4 stages;
-  // 5 = 256x256 BK32 x4 stages with the two wave halves staggered (LOAD role || MFMA role)
+  // 5 = 256x256 BK32 x4 stages with the two wave halves staggered (LOAD role || MFMA role);
+  // 6 = 256x128 BK32 x3 stages, 4 waves, TWO workgroups per CU
   const int mode = g_gemm2_mode;
   if (mode == 0) return 0;
   if (d->M % 256 || d->N % 128 || d->K % 64) return 0;
@@ -482,9 +496,9 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     if (d->a_trans == d->b_trans && d->N >= 2304 && d->N % 256 == 0) cfg = 2;
     else return 0;
   }
-  if (d->N % 256) cfg = 3;
-  const int bn = (cfg == 3) ? 128 : 256;
-  const int slots = 256;
+  if (d->N % 256 && cfg != 6) cfg = 3;
+  const int bn = (cfg == 3 || cfg == 6) ? 128 : 256;
+  const int slots = (cfg == 6) ? 512 : 256;
 
   Gemm2Args a;
   a.A = (const char*)d->A; a.B = (const char*)d->B; a.C = (char*)d->C;
@@ -529,13 +543,15 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.act = d->act; a.c_dtype = d->c_dtype;
   a.drop = make_drop(d->dropout_p, d->seed, d->site);
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
+  a.debug = g_gemm2_debug;
 
   dim3 grid(a.nblk, splits);
   int r;
-  if (cfg == 2) r = launch_cfg<256, 256, 64, 2>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else if (cfg == 3) r = launch_cfg<256, 128, 64, 3>(a, d->a_trans, d->b_trans, epi, grid, st);
+  if (cfg == 2) r = launch_cfg<256, 256, 64, 2, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
+  else if (cfg == 3) r = launch_cfg<256, 128, 64, 3, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi, grid, st);
-  else r = launch_cfg<256, 256, 32, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
+  else if (cfg == 6) r = launch_cfg<256, 128, 32, 3, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
+  else r = launch_cfg<256, 256, 32, 4, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   if (r == VIT_OK && splits > 1)
     r = launch_splitk_reduce(a.slab, (float*)d->C, (long)d->ldc, d->M, d->N, splits, d->alpha, d->accumulate, st);
   *rc = r;

@@ -67,24 +67,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // backward: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + dres,  g = dy*gamma, xhat = (x-mean)*rstd
 // per-wave running sums of dy*xhat (dgamma) and dy (dbeta) over the rows the wave visits; block-combined through LDS
 // and written as one partial row per block: part[blk][0][D] (dgamma), part[blk][1][D] (dbeta).
-template <int NV, int DY_BF16>
+// FUSE: additionally emit dyn = dropout_mask(drop) * dx as bf16 (the gradient wrt the Linear output that sits under the
+// "dropout(.) + residual" this LayerNorm's input came from) and its column sums (that Linear's bias gradient) as a
+// third partial row -- what vit_dropout_bwd_cast + vit_colsum would otherwise re-read dx for.
+template <int NV, int DY_BF16, int FUSE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ part, int rows, int D) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][D]
+                                                     float* __restrict__ dx, float* __restrict__ part, int rows, int D,
+                                                     short* __restrict__ dyn, DropCfg drop) {
+  constexpr int NP = FUSE ? 3 : 2;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][D]
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nvec = D >> 2;
   const float invD = 1.0f / (float)D;
-  f32x4 gam[NV], dg[NV], db[NV];
+  f32x4 gam[NV], dg[NV], db[NV], dbias[FUSE ? NV : 1];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     gam[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (FUSE) dbias[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   for (int row = wave; row < rows; row += nwaves) {
     const float mu = mean[row], rs = rstd[row];
@@ -120,6 +126,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         f32x4 o = (g[i] - c1 - xh[i] * c2) * rs;
         if (dres) o += *(const f32x4*)(dres + (long)row * D + 4 * c);
         *(f32x4*)(dx + (long)row * D + 4 * c) = o;
+        if (FUSE) {
+          if (drop.thr) {
+            float k0, k1, k2, k3;
+            drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)(4 * c), k0, k1);
+            drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)(4 * c) + 2, k2, k3);
+            o[0] *= k0; o[1] *= k1; o[2] *= k2; o[3] *= k3;
+          }
+          u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(u32x2*)(dyn + (long)row * D + 4 * c) = pk;
+          // sum what was stored (bf16-rounded), exactly like colsum over the bf16 tensor would
+          dbias[i] += (f32x4){bf2f((short)(pk[0] & 0xFFFF)), bf2f((short)(pk[0] >> 16)), bf2f((short)(pk[1] & 0xFFFF)),
+                              bf2f((short)(pk[1] >> 16))};
+        }
       }
     }
   }
@@ -128,16 +147,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
-      *(f32x4*)(red + (wib * 2 + 0) * D + 4 * c) = dg[i];
-      *(f32x4*)(red + (wib * 2 + 1) * D + 4 * c) = db[i];
+      *(f32x4*)(red + (wib * NP + 0) * D + 4 * c) = dg[i];
+      *(f32x4*)(red + (wib * NP + 1) * D + 4 * c) = db[i];
+      if (FUSE) *(f32x4*)(red + (wib * NP + 2) * D + 4 * c) = dbias[i];
     }
   }
   __syncthreads();
   const int nw = blockDim.x >> 6;
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
+  for (int i = threadIdx.x; i < NP * D; i += blockDim.x) {
     float a = 0.f;
-    for (int w = 0; w < nw; ++w) a += red[w * 2 * D + i];
-    part[(long)blockIdx.x * 2 * D + i] = a;
+    for (int w = 0; w < nw; ++w) a += red[w * NP * D + i];
+    part[(long)blockIdx.x * NP * D + i] = a;
   }
 }
 
@@ -158,21 +178,42 @@ static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void*
   return VIT_OK;
 }
 
-template <int DY_BF16>
+template <int DY_BF16, int FUSE>
 static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const float* mean, const float* rstd,
-                           const float* dres, float* dx, float* part, int rows, int D, int blocks, hipStream_t st) {
+                           const float* dres, float* dx, float* part, int rows, int D, int blocks, short* dyn,
+                           DropCfg drop, hipStream_t st) {
   const int nv = cdiv(D, 256);
-  const size_t sh = (size_t)4 * 2 * D * sizeof(float);
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16>), dim3(blocks), dim3(256), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D)
+  const size_t sh = (size_t)4 * (FUSE ? 3 : 2) * D * sizeof(float);
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16, FUSE>), dim3(blocks), dim3(256), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D, dyn, drop)
   if (nv <= 1) LAUNCH(1);
   else if (nv <= 2) LAUNCH(2);
   else if (nv <= 3) LAUNCH(3);
   else if (nv <= 4) LAUNCH(4);
-  else if (nv <= 8) LAUNCH(8);
-  else { set_error("vit_layernorm_bwd: D=%d > 2048 not supported", D); return VIT_ERR_UNSUPPORTED; }
+  else if (nv <= 8 && !FUSE) LAUNCH(8);
+  else { set_error("vit_layernorm_bwd: D=%d not supported (max 2048, 1024 for the fused form)", D); return VIT_ERR_UNSUPPORTED; }
 #undef LAUNCH
   VIT_LAUNCH_CHECK();
   return VIT_OK;
+}
+
+static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                         const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                         float* dbeta, int rows, int D, short* dyn, float* dbias, DropCfg drop, hipStream_t st) {
+  const int blocks = std::min(cdiv(rows, 16), 512);
+  const int np = dyn ? 3 : 2;
+  size_t wsb = 0;
+  float* part = (float*)ctx_workspace(h, &wsb);
+  const size_t need = (size_t)blocks * np * D * sizeof(float);
+  VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_layernorm_bwd: needs %zu workspace bytes, have %zu", need, wsb);
+  int rc;
+  if (dyn) rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
+                                     : ln_bwd_dispatch<0, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+  else rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
+                                 : ln_bwd_dispatch<0, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+  if (rc != VIT_OK) return rc;
+  rc = launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st, np * D);
+  if (rc != VIT_OK || !dyn) return rc;
+  return launch_reduce_partials(part + 2 * D, blocks, D, dbias, D, dbias, 0, st, np * D);
 }
 
 }  // namespace vit
@@ -197,16 +238,21 @@ int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x
   using namespace vit;
   VIT_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, VIT_ERR_ARG, "vit_layernorm_bwd: null pointer");
   VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd: rows=%d D=%d", rows, D);
-  hipStream_t st = (hipStream_t)stream;
-  const int blocks = std::min(cdiv(rows, 16), 512);
-  size_t wsb = 0;
-  float* part = (float*)ctx_workspace(h, &wsb);
-  const size_t need = (size_t)blocks * 2 * D * sizeof(float);
-  VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_layernorm_bwd: needs %zu workspace bytes, have %zu", need, wsb);
-  int rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st)
-                                : ln_bwd_dispatch<0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, st);
-  if (rc != VIT_OK) return rc;
-  return launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st);
+  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, nullptr,
+                       make_drop(0.f, 0, 0), (hipStream_t)stream);
+}
+
+int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
+                            const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
+                            float* dbeta, int rows, int D, void* dyn, float* dbias, float dropout_p, uint64_t seed,
+                            uint64_t site, vit_stream stream) {
+  using namespace vit;
+  VIT_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && dyn && dbias, VIT_ERR_ARG,
+            "vit_layernorm_bwd_fused: null pointer");
+  VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd_fused: rows=%d D=%d", rows, D);
+  VIT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, VIT_ERR_ARG, "vit_layernorm_bwd_fused: dropout_p out of [0,1)");
+  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, (short*)dyn, dbias,
+                       make_drop(dropout_p, seed, site), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -339,15 +339,17 @@ class ViTEngine:
         vf.head_loss_bwd(a["last"], self.p(hn + ".weight"), st["logits"], st["labels"], dloss, self.loss_kind,
                          dlast=t["dlast"], dW=self.g(hn + ".weight"), db=self.g(hn + ".bias"))
         dx, dx_other = t["dxa"], t["dxb"]
-        vf.layernorm_bwd(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
-                         a["rstdF"], dx=dx, dgamma=self.g("vit.layernorm.weight"), dbeta=self.g("vit.layernorm.bias"))
+        # every LayerNorm backward below also emits dy = dropout_mask * dx (bf16) and its column sums: the gradient of
+        # the Linear output underneath the next "dropout(.) + residual" going down, and that Linear's bias gradient
+        last_pre = f"vit.encoder.layer.{L - 1}."
+        vf.layernorm_bwd_fused(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
+                               a["rstdF"], None, dx, self.g("vit.layernorm.weight"), self.g("vit.layernorm.bias"),
+                               t["dy"], self.g(last_pre + "output.dense.bias"), (ph, seed, self._site(L - 1, 2)))
         if cb:
             cb(self.layout.tail_start, self.layout.n_trainable)
         for i in reversed(range(L)):
             pre = f"vit.encoder.layer.{i}."
-            # x2 = dropout(g W2^T + b2) + x1
-            vf.dropout_bwd_cast(dx, (ph, seed, self._site(i, 2)), out=t["dy"])
-            vf.colsum(t["dy"], out=self.g(pre + "output.dense.bias"))
+            # x2 = dropout(g W2^T + b2) + x1      (t["dy"] = mask * dx and db2 were produced by the LN backward above)
             vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=M, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
                     split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=M, N=Fd, K=D, b_trans=True, out=t["dU"],
@@ -356,13 +358,12 @@ class ViTEngine:
             vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=M, a_trans=True, b_trans=True,
                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
             vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=M, N=D, K=Fd, b_trans=True, out=t["dh"])
-            vf.layernorm_bwd(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i], a["rstd2"][i],
-                             dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_after.weight"),
-                             dbeta=self.g(pre + "layernorm_after.bias"))
+            # x1 = dropout(ctx Wo^T + bo) + x:  LN2 backward -> dx1, and dya = mask * dx1 with dbo
+            vf.layernorm_bwd_fused(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i],
+                                   a["rstd2"][i], dx, dx_other, self.g(pre + "layernorm_after.weight"),
+                                   self.g(pre + "layernorm_after.bias"), t["dy"],
+                                   self.g(pre + "attention.output.dense.bias"), (ph, seed, self._site(i, 1)))
             dx, dx_other = dx_other, dx
-            # x1 = dropout(ctx Wo^T + bo) + x
-            vf.dropout_bwd_cast(dx, (ph, seed, self._site(i, 1)), out=t["dy"])
-            vf.colsum(t["dy"], out=self.g(pre + "attention.output.dense.bias"))
             vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=M, a_trans=True, b_trans=True,
                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, b_trans=True, out=t["dctx"])
@@ -372,9 +373,17 @@ class ViTEngine:
             vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=M, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
                     split_k=-1)
             vf.gemm(t["dqkv"], self._qkv16(i), M=M, N=D, K=3 * D, b_trans=True, out=t["dh"])
-            vf.layernorm_bwd(t["dh"], a["x"][i].view(M, D), self.p(pre + "layernorm_before.weight"), a["mean1"][i],
-                             a["rstd1"][i], dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_before.weight"),
-                             dbeta=self.g(pre + "layernorm_before.bias"))
+            if i > 0:
+                # LN1 backward -> dx (input of this layer = output of layer i-1), plus layer i-1's FC2 pieces
+                prev = f"vit.encoder.layer.{i - 1}."
+                vf.layernorm_bwd_fused(t["dh"], a["x"][i].view(M, D), self.p(pre + "layernorm_before.weight"),
+                                       a["mean1"][i], a["rstd1"][i], dx, dx_other,
+                                       self.g(pre + "layernorm_before.weight"), self.g(pre + "layernorm_before.bias"),
+                                       t["dy"], self.g(prev + "output.dense.bias"), (ph, seed, self._site(i - 1, 2)))
+            else:
+                vf.layernorm_bwd(t["dh"], a["x"][i].view(M, D), self.p(pre + "layernorm_before.weight"), a["mean1"][i],
+                                 a["rstd1"][i], dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_before.weight"),
+                                 dbeta=self.g(pre + "layernorm_before.bias"))
             dx, dx_other = dx_other, dx
             if cb:
                 cb(*self.layout.layer_ranges[i])

@@ -129,6 +129,20 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dx=None, dgamma=None, dbe
     return dx, dgamma, dbeta
 
 
+def layernorm_bwd_fused(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dyn, dbias, dropout: Dropout = NO_DROP):
+    """LayerNorm backward that also emits dyn = mask * dx (bf16) and dbias = colsum(dyn)."""
+    _chk(x, torch.float32, "layernorm_bwd_fused x")
+    h = _h(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    p, seed, site = dropout
+    check(h.lib.vit_layernorm_bwd_fused(h.h, dy.data_ptr(), _DT[dy.dtype], x.data_ptr(), gamma.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
+                                        dbeta.data_ptr(), rows, D, dyn.data_ptr(), dbias.data_ptr(), p, seed, site,
+                                        _stream(x)), "vit_layernorm_bwd_fused")
+    return dx, dgamma, dbeta, dyn, dbias
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP, ctx=None, lse=None):
     _chk(qkv, torch.bfloat16, "attention_fwd qkv")
