@@ -88,6 +88,9 @@ typedef struct vit_gemm_desc {
   int accumulate;          /* split_k path: C += result instead of C = result */
 } vit_gemm_desc;
 int vit_gemm(vit_handle h, const vit_gemm_desc* d, vit_stream stream);
+/* Symbol (as rocprofv3 prints it, without the "void vit::" prefix and argument list) of the kernel the calling thread's
+ * last vit_gemm launched: lets a benchmark attribute its per-call timings to the kernels a profiler lists. */
+const char* vit_last_gemm_kernel(void);
 
 /* Convenience forms named after SURVEY.md section 8b.  x:[M,K] bf16, W:[N,K] bf16 (nn.Linear layout), y:[M,N]. */
 int vit_linear_fwd(vit_handle h, const void* x, const void* W, const float* bias, void* y, int y_dtype, int M, int N,

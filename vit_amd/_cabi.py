@@ -54,6 +54,7 @@ _PROTOS = {
     "vit_set_workspace": [_P, _P, _SZ],
     "vit_set_option": [C.c_char_p, _I],
     "vit_gemm": [_P, C.POINTER(GemmDesc), _P],
+    "vit_last_gemm_kernel": [],
     "vit_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _U64, _U64, _P, _P],
     "vit_linear_bwd_dx": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vit_linear_bwd_dw": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -74,7 +75,7 @@ _PROTOS = {
     "vit_grad_sqnorm": [_P, _P, _I64, _P, _P],
     "vit_adamw_step": [_P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I, _P, _F, _P],
 }
-_RESTYPES = {"vit_last_error": C.c_char_p}
+_RESTYPES = {"vit_last_error": C.c_char_p, "vit_last_gemm_kernel": C.c_char_p}
 
 _lib = None
 _lock = threading.Lock()

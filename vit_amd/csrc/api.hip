@@ -16,6 +16,7 @@ namespace vit {
 extern int g_gemm2_mode, g_gemm2_debug;  // gemm2.hip
 
 static thread_local char g_err[512] = "";
+thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -62,6 +63,8 @@ int vit_destroy(vit_handle h) {
   delete h;
   return VIT_OK;
 }
+
+const char* vit_last_gemm_kernel(void) { return vit::g_last_gemm; }
 
 int vit_set_option(const char* name, int value) {
   VIT_CHECK(name, VIT_ERR_ARG, "vit_set_option: null name");

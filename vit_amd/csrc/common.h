@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+extern thread_local char g_last_gemm[96];
 #define VIT_CHECK(cond, code, ...)            \
   do {                                         \
     if (!(cond)) {                             \

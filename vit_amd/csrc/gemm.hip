@@ -18,6 +18,7 @@
 // The MFMA is issued with the operands swapped (B-fragment as matrix A), so a lane ends up with 4 CONSECUTIVE
 // columns n of one row m: bias/aux/residual loads and the C store are 8/16-byte vectors.
 #include <algorithm>
+#include <stdio.h>
 
 #include "common.h"
 
@@ -373,6 +374,7 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
 
   dim3 grid(a.tiles_m * a.tiles_n, splits), block(NTHR);
   const int v = d->a_trans * 2 + d->b_trans;
+  snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm_bf16_kernel<%d, %d>", d->a_trans, d->b_trans);
   switch (v) {
     case 0: hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, block, 0, st, a); break;

@@ -23,6 +23,7 @@
 //   transposed:          k-row k, 8-B chunk ch at k*2R + ((ch ^ tr_swz(k)) << 3),  tr_swz(k) = ((k&3) | ((k>>3)&1)<<2) << 2
 // all conflict-free for the 16x16x32 operand reads (ds_read_b128 / ds_read_b64_tr_b16): SQ_LDS_BANK_CONFLICT = 0.
 #include <algorithm>
+#include <stdio.h>
 
 #include "common.h"
 
@@ -546,6 +547,13 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.debug = g_gemm2_debug;
 
   dim3 grid(a.nblk, splits);
+  {
+    static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
+    const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
+    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d>", at, bt, epi);
+    else snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", geo[cfg][0], geo[cfg][1],
+                  geo[cfg][2], geo[cfg][3], geo[cfg][4], at, bt, epi);
+  }
   int r;
   if (cfg == 2) r = launch_cfg<256, 256, 64, 2, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   else if (cfg == 3) r = launch_cfg<256, 128, 64, 3, 8>(a, d->a_trans, d->b_trans, epi, grid, st);

@@ -31,7 +31,8 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VIT_DIST_BACKEND=gloo lets several ranks share ONE GPU for rehearsals (RCCL refuses duplicate devices)
+            backend = os.environ.get("VIT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -87,6 +88,8 @@ class GradAllReducer:
                 w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
                 self._pending.append((w, None))
             else:
+                if t.is_cuda:  # gloo reads the tensor on the host side: the producing kernels must have finished
+                    torch.cuda.current_stream(t.device).synchronize()
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._pending.append((w, t))
             self.bytes_reduced += t.numel() * t.element_size()

@@ -63,6 +63,7 @@ class Trainer:
         self.acc, self.device0 = select_accelerator_and_devices(config.get("gpus"))
         self.strategy = get_training_strategy(self.world)
         self.device = device or torch.device("cuda", self.local_rank)
+        self.backend = torch.distributed.get_backend() if self.world > 1 else None
         self.verbose = verbose and self.rank == 0
         self.logged: Dict[str, float] = {}
         self._epoch_acc: Dict[str, list] = {}
