@@ -120,8 +120,8 @@ int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x
  * column sums (that Linear's bias gradient): one pass instead of vit_dropout_bwd_cast + vit_colsum re-reading dx. */
 int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
                             const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
-                            float* dbeta, int rows, int D, void* dyn, float* dbias, float dropout_p, uint64_t seed,
-                            uint64_t site, vit_stream stream);
+                            float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, float dropout_p,
+                            uint64_t seed, uint64_t site, vit_stream stream);
 
 /* ------------------------------------------------------------------------------------------- Attention
  * softmax(Q K^T * scale) -> dropout -> * V, per (batch, head); flash-style (scores never reach HBM).
@@ -130,34 +130,38 @@ int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const fl
  * columns h*dh (the fused QKV projection's natural output; equals view(B,T,H,dh).transpose(1,2) of each third).
  * ctx: bf16 [B*T, H*dh] (= context_layer after transpose+view, vit_with_rope.py:75-78); lse: f32 [B*H, T]
  * (log-sum-exp of the scaled scores, saved for backward).
+ * io_dtype = VIT_BF16: the MFMA flash kernels (qkv / ctx / dctx / dqkv bf16).  io_dtype = VIT_F32: the same tensors in
+ * f32 and exact fp32 arithmetic (the precision='32' path; T <= 4096).
  */
-int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int B, int H, int T, int dh, float scale,
-                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
+int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int io_dtype, int B, int H, int T, int dh,
+                      float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
 /* dqkv: bf16 [B*T, 3*H*dh] from dctx: bf16 [B*T, H*dh]; recomputes probabilities from lse. delta: f32 [B*H, T]
  * scratch (rowsum(dctx*ctx)), written by this call. */
 int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                      float* delta, void* dqkv, int B, int H, int T, int dh, float scale, float dropout_p,
-                      uint64_t seed, uint64_t site, vit_stream stream);
+                      float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
 /* Attention probabilities [B, H, T, T] f32 (eval-mode, for output_attentions=True: specvit.py:92-93). */
-int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int B, int H, int T, int dh, float scale,
-                        vit_stream stream);
+int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtype, int B, int H, int T, int dh,
+                        float scale, vit_stream stream);
 
 /* ------------------------------------------------------------------------------- Embedding-side kernels
- * x.unfold(1,P,S) (+ zero pad of the ragged tail patch) -> bf16 patches [B*N, P]   (tokenization.py:45-49) */
-int vit_unfold_cast(vit_handle h, const float* x, void* patches, int B, int L, int P, int S, int N, vit_stream stream);
+ * x.unfold(1,P,S) (+ zero pad of the ragged tail patch) -> patches [B*N, P] (bf16 or f32)   (tokenization.py:45-49) */
+int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, int B, int L, int P, int S, int N,
+                    vit_stream stream);
 /* rows 0 of every sample <- cls_token (embedding.py:87-88); optional "+ position_embeddings" (embedding.py:95-97)
  * and the embedding dropout (embedding.py:100) over the whole [B, T, D] f32 token tensor, in place. */
 int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float* pos, int B, int T, int D,
                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
 /* backward of the two above: dtokens [B,T,D] f32 -> dpatch_out bf16 [B*N, D] (dropout mask applied), dcls [D],
  * dpos [T,D] or NULL. */
-int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, float* dcls, float* dpos, int B, int T,
-                         int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate, vit_stream stream);
+int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, int dpatch_dtype, float* dcls, float* dpos,
+                         int B, int T, int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate,
+                         vit_stream stream);
 
 /* ------------------------------------------------------------------------------- Elementwise / reductions
- * dy (bf16 [rows, cols]) = dropout_mask(seed,site) * dx (f32); also the gradient of "dropout(y) + residual" wrt y */
-int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int rows, int cols, float dropout_p, uint64_t seed,
-                         uint64_t site, vit_stream stream);
+ * dy ([rows, cols], bf16 or f32) = dropout_mask(seed,site) * dx (f32): the gradient of "dropout(y) + residual" wrt y */
+int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int dy_dtype, int rows, int cols, float dropout_p,
+                         uint64_t seed, uint64_t site, vit_stream stream);
 /* out[cols] (f32) (+)= column sums of a [rows, cols] tensor (bias gradients), deterministic two-stage */
 int vit_colsum(vit_handle h, const void* a, int a_dtype, int64_t lda, float* out, int rows, int cols, int accumulate,
                vit_stream stream);

@@ -457,3 +457,73 @@ def test_layernorm_bwd_fused(dev, rows, D):
                                                              E(rows, D, dt=torch.bfloat16), E(D), drop)
         assert torch.equal(dx1, dx0) and torch.equal(dyn1, dyn0)
         assert rel(dg1, dg0) < 1e-6 and rel(db1, db0) < 1e-6 and rel(dbias1, dbias0) < 1e-5
+
+
+# ------------------------------------------------------------------ fp32-class kernels (precision='32')
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 192, 192), (104, 40, 72), (516, 96, 32), (1024, 768, 768)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+def test_gemm_x3_f32_operands(dev, M, N, K, layout):
+    """Split-bf16 x3 GEMM on f32 operands against an fp64 reference: ~1e-5 relative."""
+    import vit_amd.functional as vf
+
+    a_t, b_t = layout in ("tn", "tt"), layout in ("nn", "tn")
+    if a_t and M % 8:
+        pytest.skip("transposed A needs M % 8 == 0")
+    A, Bm = randn((M, K), dev, 1), randn((N, K), dev, 2)
+    ref = (A.double() @ Bm.double().t()).float()
+    a_store = A.t().contiguous() if a_t else A
+    b_store = Bm.t().contiguous() if b_t else Bm
+    out = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.float32)
+    assert rel(out, ref) < 3e-5, (layout, rel(out, ref))
+    sk = vf.gemm(a_store, b_store, M=M, N=N, K=K, a_trans=a_t, b_trans=b_t, out_dtype=torch.float32, split_k=-1)
+    assert rel(sk, ref) < 3e-5
+
+
+def test_gemm_x3_epilogues(dev):
+    import vit_amd.functional as vf
+    from vit_amd._cabi import ACT_GELU
+
+    M, N, K = 330, 256, 192
+    x, W = randn((M, K), dev, 3), randn((N, K), dev, 4, 0.1)
+    bias, res = randn((N,), dev, 5), randn((M, N), dev, 6)
+    base = (x.double() @ W.double().t()).float() + bias
+    aux = torch.empty((M, N), dtype=torch.float32, device=dev)
+    y = vf.linear_fwd(x, W, bias, out_dtype=torch.float32, act=ACT_GELU, aux_out=aux)
+    assert rel(aux, base) < 3e-5 and rel(y, F.gelu(base)) < 3e-5
+    y = vf.linear_fwd(x, W, bias, out_dtype=torch.float32, residual=res)
+    assert rel(y, base + res) < 3e-5
+    dy, u = randn((M, N), dev, 7), randn((M, K), dev, 8)
+    dx = vf.linear_bwd_dx(dy, W, dgelu_aux=u, out_dtype=torch.float32)
+    uu = u.clone().requires_grad_(True)
+    F.gelu(uu).backward((dy.double() @ W.double()).float())
+    assert rel(dx, uu.grad) < 3e-5
+    dw = vf.linear_bwd_dw(dy, x)
+    assert rel(dw, (dy.double().t() @ x.double()).float()) < 3e-5
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 5, 64), (1, 2, 197, 64), (1, 1, 70, 128)])
+def test_attention_f32(dev, B, H, T, dh):
+    import vit_amd.functional as vf
+
+    scale = dh ** -0.5
+    qkv = randn((B * T, 3 * H * dh), dev, 30)
+    ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, scale)
+    q32 = qkv.clone().requires_grad_(True)
+    ref, p, lse_ref = attn_ref(q32, B, H, T, dh, scale)
+    assert rel(ctx, ref) < 1e-5 and rel(lse, lse_ref.reshape(B * H, T)) < 1e-6
+    assert rel(vf.attention_probs(qkv, B, H, T, dh, scale), p) < 1e-5
+    dctx = randn((B * T, H * dh), dev, 31)
+    ref.backward(dctx)
+    dqkv = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale)
+    assert rel(dqkv, q32.grad) < 2e-5
+    # dropout: same mask function as the bf16 kernels (row = bh*T + q, column pair = key / 2)
+    drop = (0.1, 99, 3)
+    mask = extract_attn_mask(vf, dev, B, H, T, dh, drop) if dh <= 64 else None
+    if mask is not None:
+        mask = (mask > 0.5).float() * (65536.0 / (65536 - 6554))
+        ctxd, lsed = vf.attention_fwd(qkv, B, H, T, dh, scale, dropout=drop)
+        q32 = qkv.clone().requires_grad_(True)
+        refd, _, _ = attn_ref(q32, B, H, T, dh, scale, mask)
+        assert rel(ctxd, refd) < 1e-5
+        refd.backward(dctx)
+        assert rel(vf.attention_bwd(qkv, ctxd, dctx, lsed, B, H, T, dh, scale, dropout=drop), q32.grad) < 2e-5

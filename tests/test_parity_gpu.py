@@ -2,7 +2,10 @@
 own modules (tests/golden/*.npz, oracle/make_golden.py) and with the CPU oracle on the same seeded inputs.
 
 Tolerances (stated per north_star):
-  * the MFMA contractions consume bf16 operands (fp32 accumulate, fp32 residual stream / LN / softmax statistics), i.e.
+  * precision='32' (the reference's default; split-bf16 x3 GEMMs + fp32 attention / LayerNorm): the north_star gate
+    "forward within 1e-3 rel of reference" is asserted at 1e-4 on every hidden state, attention map and the logits
+    (measured <= 1.2e-5), gradients at 2e-4 per tensor (measured <= 1.7e-5), 3-step loss trajectory at 5e-4.
+  * precision='bf16-mixed': the MFMA contractions consume bf16 operands (fp32 accumulate, fp32 residual stream / LN / softmax statistics), i.e.
     the arithmetic of the reference under precision='bf16-mixed'.  The fixtures hold the reference's fp32 outputs AND
     its own bf16-autocast outputs; the reference's bf16 run differs from its fp32 run by 4e-3..7e-3 (relative L2), so a
     1e-3 match to the fp32 outputs is not reachable by ANY bf16 pipeline.  The gate is therefore:
@@ -27,7 +30,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def setup(tag, dev):
+def setup(tag, dev, precision="bf16-mixed"):
     from oracle import refvit
     from vit_amd.config import ViTConfig
     from vit_amd.specvit import MyViT
@@ -50,6 +53,7 @@ def setup(tag, dev):
                     num_attention_heads=rc.num_attention_heads, proj_fn=rc.proj_fn, stride_size=rc.stride_size,
                     num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type)
     model = MyViT(cfg, loss_name=rc.loss_name)
+    model.set_precision(precision)
     missing = model.load_state_dict(sd, strict=True)
     model = model.to(dev)
     x = torch.from_numpy(g["flux"]).to(dev)
@@ -235,3 +239,65 @@ def test_cpu_tensor_fails_loudly():
     m = MyViT(cfg, loss_name="mae")
     with pytest.raises(VitError):
         m(torch.zeros(2, 256), labels=torch.zeros(2))
+
+
+# ------------------------------------------------------------------ precision='32' (the reference's default): fp32-class
+@pytest.mark.parametrize("tag", ["c1", "c2", "r1", "k1"])
+def test_f32_mode_forward_within_1e3_of_reference(dev, tag):
+    """north_star's gate, literally: forward within 1e-3 (relative L2) of the reference's fp32 outputs -- here on every
+    hidden state, attention map, the logits and the loss, with the split-bf16 x3 GEMMs / fp32 attention / fp32 LN."""
+    rc, g, sd, model, x, labels = setup(tag, dev, precision="32")
+    model.eval()
+    out = model(x, labels=labels, output_hidden_states=True, output_attentions=True)
+    T = lambda k: torch.from_numpy(g[k])
+    hs = torch.stack([h.cpu() for h in out.hidden_states])
+    errs = [rel(hs[i], T("hidden_states")[i]) for i in range(hs.shape[0])]
+    e_att = max(rel(out.attentions[0], T("attn0")), rel(out.attentions[-1], T("attn_last")))
+    e_log = rel(out.logits, T("logits"))
+    print(f"[{tag}] f32 mode: hidden states max {max(errs):.2e}, attention {e_att:.2e}, logits {e_log:.2e}")
+    # gate: 1e-3 (north_star); measured on MI355X: <= 1.2e-5 everywhere -- assert an order of magnitude inside the gate
+    assert max(errs) < 1e-4 and e_att < 1e-4 and e_log < 1e-4
+    assert abs(float(out.loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"])) + 1e-7
+
+
+@pytest.mark.parametrize("tag", ["c1", "r1", "k1"])
+def test_f32_mode_gradients_and_steps(dev, tag):
+    from vit_amd.optimizer import FusedAdamW
+
+    rc, g, sd, model, x, labels = setup(tag, dev, precision="32")
+    model.eval()
+    model(x, labels=labels).loss.backward()
+    names = [str(n) for n in g["param_names"]]
+    gn = g["grad_norms"]
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if f"grad/{name}" not in g.files:
+            assert p.grad is None
+            continue
+        if gn[names.index(name)] < 1e-6:
+            continue
+        e = rel(p.grad.detach().cpu().flatten(), torch.from_numpy(g[f"grad/{name}"]).flatten())
+        worst = max(worst, e)
+        assert e < 2e-4, (name, e)  # measured <= 1.7e-5
+    print(f"[{tag}] f32 mode: worst gradient rel err {worst:.2e}")
+    # three optimisation steps against the oracle's trajectory (dropout off)
+    rc, g, sd, model, x, labels = setup(tag, dev, precision="32")
+    model.eval()
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.set_grad_clip(0.5)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model(x, labels=labels).loss
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.allclose(losses, g["step_losses"], rtol=5e-4), (losses, g["step_losses"])
+
+
+def test_f32_mode_train_step_runs_with_dropout(dev):
+    rc, g, sd, model, x, labels = setup("c1", dev, precision="32")
+    model.train()
+    l1 = model(x, labels=labels).loss
+    l1.backward()
+    assert torch.isfinite(l1) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

@@ -60,14 +60,14 @@ _PROTOS = {
     "vit_linear_bwd_dw": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vit_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     "vit_layernorm_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
-    "vit_layernorm_bwd_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _F, _U64, _U64, _P],
-    "vit_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
-    "vit_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
-    "vit_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "vit_unfold_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vit_layernorm_bwd_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _F, _U64, _U64, _P],
+    "vit_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
+    "vit_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
+    "vit_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vit_unfold_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vit_embed_finish": [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],
-    "vit_embed_finish_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
-    "vit_dropout_bwd_cast": [_P, _P, _P, _I, _I, _F, _U64, _U64, _P],
+    "vit_embed_finish_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
+    "vit_dropout_bwd_cast": [_P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],
     "vit_colsum": [_P, _P, _I, _I64, _P, _I, _I, _I, _P],
     "vit_cast_f32_bf16": [_P, _P, _P, _I64, _P],
     "vit_head_loss_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -881,6 +881,179 @@ static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
     else { constexpr int DH_ = 64; rc = launch_res(KERNEL<64, RES_RQ>, a, smem_expr, st); }                    \
   } while (0)
 
+// ======================================================================================= fp32 attention (precision '32')
+// Exact-arithmetic path behind the reference's default precision: fp32 in, fp32 FMAs, fp32 out; one wave per query row
+// (forward, dQ) or key row (dK/dV); scores / probabilities of the row live in the wave's LDS slice.  The fp32 matrix
+// instructions run at the vector rate on gfx950, so nothing is lost by using the vector units; this path is for
+// parity-grade runs, the bf16 kernels above are the throughput path.  qkv: f32 [B*T, 3*H*dh].
+struct Attn32Args {
+  const float* qkv; float* ctx; float* lse; float* probs;
+  const float* dctx; float* delta; float* dqkv;
+  int B, H, T, dh, Tp;
+  float scale;
+  DropCfg drop;
+};
+
+__device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned long long row, unsigned half_cols, unsigned col) {
+  if (!d.thr) return 1.f;
+  const unsigned h = drop_hash(d.k0, d.k1, row * half_cols + (col >> 1));
+  const unsigned r16 = (col & 1) ? (h >> 16) : (h & 0xFFFFu);
+  return r16 >= d.thr ? d.scale : 0.f;
+}
+__device__ __forceinline__ float dot_row(const float* __restrict__ a_lds, const float* __restrict__ g, int dh) {
+  float s = 0.f;
+  for (int d = 0; d < dh; d += 4) {
+    const f32x4 x = *(const f32x4*)(a_lds + d), y = *(const f32x4*)(g + d);
+    s = fmaf(x[0], y[0], s); s = fmaf(x[1], y[1], s); s = fmaf(x[2], y[2], s); s = fmaf(x[3], y[3], s);
+  }
+  return s;
+}
+
+// MODE 0: forward (ctx, lse, optional probs)   MODE 1: dQ (+ delta)
+template <int MODE>
+__global__ __launch_bounds__(256) void attn32_row_kernel(Attn32Args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm32[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wib;  // (b*H + h)*T + q
+  if (row >= (long)p.B * p.H * p.T) return;      // whole waves only; no block barrier is used below
+  const int T = p.T, dh = p.dh, H = p.H;
+  const int q = (int)(row % T);
+  const long bh = row / T;
+  const int h = (int)(bh % H);
+  const long b = bh / H;
+  const long ld = 3L * H * dh, ldc = (long)H * dh;
+  float* pr = sm32 + wib * (2 * p.Tp + 2 * 128);  // [Tp] p or p*mask, [Tp] ds, [128] q row, [128] dO row
+  float* ds = pr + p.Tp;
+  float* qrow = ds + p.Tp;
+  float* dorow = qrow + 128;
+  const float* qp = p.qkv + (b * T + q) * ld + h * dh;
+  const float* kbase = p.qkv + b * T * ld + H * dh + h * dh;
+  const float* vbase = kbase + H * dh;
+  for (int d = lane; d < dh; d += 64) {
+    qrow[d] = qp[d];
+    if (MODE == 1) dorow[d] = p.dctx[(b * T + q) * ldc + h * dh + d];
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; this only pins the compiler's schedule
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+  const unsigned long long drow = (unsigned long long)row;
+  if (MODE == 0) {
+    float mx = -INFINITY;
+    for (int k = lane; k < T; k += 64) {
+      const float sc = dot_row(qrow, kbase + (long)k * ld, dh) * p.scale;
+      pr[k] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < T; k += 64) {
+      const float e = expf(pr[k] - mx);
+      pr[k] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int k = lane; k < T; k += 64) {
+      const float pk = pr[k] * inv;
+      if (p.probs) p.probs[row * T + k] = pk;
+      pr[k] = pk * drop_mult(p.drop, drow, half_cols, (unsigned)k);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (p.lse && lane == 0) p.lse[row] = mx + logf(sum);
+    if (p.ctx) {
+      for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int k = 0; k < T; ++k) acc = fmaf(pr[k], vbase[(long)k * ld + d], acc);
+        p.ctx[(b * T + q) * ldc + h * dh + d] = acc;
+      }
+    }
+  } else {
+    const float lse = p.lse[row];
+    float dl = 0.f;
+    for (int d = lane; d < dh; d += 64) dl = fmaf(dorow[d], p.ctx[(b * T + q) * ldc + h * dh + d], dl);
+    dl = wave_sum(dl);
+    if (lane == 0) p.delta[row] = dl;
+    for (int k = lane; k < T; k += 64) {
+      const float sc = dot_row(qrow, kbase + (long)k * ld, dh) * p.scale;
+      const float pk = expf(sc - lse);
+      const float dp = dot_row(dorow, vbase + (long)k * ld, dh);
+      ds[k] = pk * (dp * drop_mult(p.drop, drow, half_cols, (unsigned)k) - dl);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < dh; d += 64) {
+      float acc = 0.f;
+      for (int k = 0; k < T; ++k) acc = fmaf(ds[k], kbase[(long)k * ld + d], acc);
+      p.dqkv[(b * T + q) * ld + h * dh + d] = acc * p.scale;
+    }
+  }
+}
+
+// dK, dV: one wave per key row
+__global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32Args p) {
+  extern __shared__ __attribute__((aligned(16))) float sm32[];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wib;  // (b*H + h)*T + key
+  if (row >= (long)p.B * p.H * p.T) return;
+  const int T = p.T, dh = p.dh, H = p.H;
+  const int key = (int)(row % T);
+  const long bh = row / T;
+  const int h = (int)(bh % H);
+  const long b = bh / H;
+  const long ld = 3L * H * dh, ldc = (long)H * dh;
+  float* pd = sm32 + wib * (2 * p.Tp + 2 * 128);
+  float* ds = pd + p.Tp;
+  float* krow = ds + p.Tp;
+  float* vrow = krow + 128;
+  const float* qbase = p.qkv + b * T * ld + h * dh;
+  const float* kp = qbase + (long)key * ld + H * dh;
+  const float* dobase = p.dctx + b * T * ldc + h * dh;
+  for (int d = lane; d < dh; d += 64) {
+    krow[d] = kp[d];
+    vrow[d] = kp[H * dh + d];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+  for (int q = lane; q < T; q += 64) {
+    const float sc = dot_row(krow, qbase + (long)q * ld, dh) * p.scale;
+    const float pk = expf(sc - p.lse[bh * T + q]);
+    const float dp = dot_row(vrow, dobase + (long)q * ldc, dh);
+    const float m = drop_mult(p.drop, (unsigned long long)(bh * T + q), half_cols, (unsigned)key);
+    pd[q] = pk * m;
+    ds[q] = pk * (dp * m - p.delta[bh * T + q]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = lane; d < dh; d += 64) {
+    float av = 0.f, ak = 0.f;
+    for (int q = 0; q < T; ++q) {
+      av = fmaf(pd[q], dobase[(long)q * ldc + d], av);
+      ak = fmaf(ds[q], qbase[(long)q * ld + d], ak);
+    }
+    float* o = p.dqkv + (b * T + key) * ld + H * dh + h * dh + d;
+    o[0] = ak * p.scale;
+    o[H * dh] = av;
+  }
+}
+
+static int launch_attn32(int which, Attn32Args& a, hipStream_t st) {
+  VIT_CHECK(a.T <= 4096 && a.dh <= 128 && (a.dh % 4) == 0, VIT_ERR_UNSUPPORTED,
+            "fp32 attention supports T <= 4096 and dh <= 128 (multiple of 4); got T=%d dh=%d", a.T, a.dh);
+  a.Tp = (a.T + 63) & ~63;
+  const size_t smem = (size_t)4 * (2 * a.Tp + 256) * sizeof(float);
+  const long rows = (long)a.B * a.H * a.T;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  static bool attr[3] = {false, false, false};
+  const void* fns[3] = {(const void*)attn32_row_kernel<0>, (const void*)attn32_row_kernel<1>, (const void*)attn32_dkv_kernel};
+  if (!attr[which]) {
+    VIT_HIP(hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr[which] = true;
+  }
+  if (which == 0) hipLaunchKernelGGL(attn32_row_kernel<0>, grid, block, smem, st, a);
+  else if (which == 1) hipLaunchKernelGGL(attn32_row_kernel<1>, grid, block, smem, st, a);
+  else hipLaunchKernelGGL(attn32_dkv_kernel, grid, block, smem, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
 static int check_attn(const char* fn, int B, int H, int T, int dh, float p) {
   VIT_CHECK(B > 0 && H > 0 && T > 0 && dh > 0, VIT_ERR_ARG, "%s: B=%d H=%d T=%d dh=%d", fn, B, H, T, dh);
   VIT_CHECK((dh % 8) == 0 && dh <= 128, VIT_ERR_UNSUPPORTED, "%s: head dim %d (need a multiple of 8, <= 128)", fn, dh);
@@ -900,12 +1073,19 @@ static int check_attn(const char* fn, int B, int H, int T, int dh, float p) {
 extern "C" {
 using namespace vit;
 
-int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int B, int H, int T, int dh, float scale,
-                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
+int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int io_dtype, int B, int H, int T, int dh,
+                      float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && ctx && lse, VIT_ERR_ARG, "vit_attention_fwd: null pointer");
   int rc = check_attn("vit_attention_fwd", B, H, T, dh, dropout_p);
   if (rc != VIT_OK) return rc;
+  if (io_dtype == VIT_F32) {
+    Attn32Args a32 = {};
+    a32.qkv = (const float*)qkv; a32.ctx = (float*)ctx; a32.lse = lse;
+    a32.B = B; a32.H = H; a32.T = T; a32.dh = dh; a32.scale = scale;
+    a32.drop = make_drop(dropout_p, seed, site);
+    return launch_attn32(0, a32, (hipStream_t)stream);
+  }
   AttnArgs a = {};
   a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
@@ -922,13 +1102,23 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
 }
 
 int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                      float* delta, void* dqkv, int B, int H, int T, int dh, float scale, float dropout_p,
-                      uint64_t seed, uint64_t site, vit_stream stream) {
+                      float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                      float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && ctx && dctx && lse && delta && dqkv, VIT_ERR_ARG, "vit_attention_bwd: null pointer");
   int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
   if (rc != VIT_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
+  if (io_dtype == VIT_F32) {
+    Attn32Args a32 = {};
+    a32.qkv = (const float*)qkv; a32.ctx = (float*)const_cast<void*>(ctx); a32.lse = const_cast<float*>(lse);
+    a32.dctx = (const float*)dctx; a32.delta = delta; a32.dqkv = (float*)dqkv;
+    a32.B = B; a32.H = H; a32.T = T; a32.dh = dh; a32.scale = scale;
+    a32.drop = make_drop(dropout_p, seed, site);
+    rc = launch_attn32(1, a32, st);
+    if (rc != VIT_OK) return rc;
+    return launch_attn32(2, a32, st);
+  }
   AttnArgs a = {};
   a.qkv = (const short*)qkv; a.lse = const_cast<float*>(lse); a.ctx = (short*)const_cast<void*>(ctx);
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
@@ -949,12 +1139,19 @@ int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void
   return VIT_OK;
 }
 
-int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int B, int H, int T, int dh, float scale,
-                        vit_stream stream) {
+int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtype, int B, int H, int T, int dh,
+                        float scale, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && probs, VIT_ERR_ARG, "vit_attention_probs: null pointer");
   int rc = check_attn("vit_attention_probs", B, H, T, dh, 0.f);
   if (rc != VIT_OK) return rc;
+  if (io_dtype == VIT_F32) {
+    Attn32Args a32 = {};
+    a32.qkv = (const float*)qkv; a32.probs = probs;
+    a32.B = B; a32.H = H; a32.T = T; a32.dh = dh; a32.scale = scale;
+    a32.drop = make_drop(0.f, 0, 0);
+    return launch_attn32(0, a32, (hipStream_t)stream);
+  }
   const long rows = (long)B * H * T;
   hipLaunchKernelGGL(attn_probs_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const short*)qkv, probs, B, H, T, dh, scale);

@@ -16,7 +16,8 @@ static inline int grid_for(long n, int block = 256, int cap = 4096) {
 // ------------------------------------------------------------------------------------------ unfold + cast
 // patches[(b*N+n)*P + p] = bf16(x[b*L + n*S + p]); a window that does not fit entirely inside the signal is ALL zero:
 // Tensor.unfold drops partial windows and the reference appends whole zero patches (tokenization.py:45-49)
-__global__ void unfold_cast_kernel(const float* __restrict__ x, short* __restrict__ out, int B, int L, int P, int S,
+template <int OUT_BF16>
+__global__ void unfold_cast_kernel(const float* __restrict__ x, void* __restrict__ out, int B, int L, int P, int S,
                                    int N) {
   const long total = (long)B * N * (P >> 2);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -29,8 +30,12 @@ __global__ void unfold_cast_kernel(const float* __restrict__ x, short* __restric
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = (n * S + P <= L) ? src[k] : 0.f;
-    u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-    *(u32x2*)(out + bn * P + pv) = pk;
+    if (OUT_BF16) {
+      u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)((short*)out + bn * P + pv) = pk;
+    } else {
+      *(f32x4*)((float*)out + bn * P + pv) = (f32x4){v[0], v[1], v[2], v[3]};
+    }
   }
 }
 
@@ -58,7 +63,8 @@ __global__ void embed_finish_kernel(float* __restrict__ tok, const float* __rest
 
 // one thread per (t, 4 columns): walks the batch, applies the embedding-dropout mask, emits the bf16 gradient of the
 // patch projection output (rows t >= 1) and the batch-summed gradients of cls_token (t == 0) / position_embeddings.
-__global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, short* __restrict__ dpatch,
+template <int OUT_BF16>
+__global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, void* __restrict__ dpatch,
                                         float* __restrict__ dcls, float* __restrict__ dpos, int B, int T, int D,
                                         DropCfg drop, int accumulate) {
   const int dv = D >> 2;
@@ -79,8 +85,12 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, short* _
     }
     acc += v;
     if (t > 0) {
-      u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-      *(u32x2*)(dpatch + ((long)b * N + (t - 1)) * D + d) = pk;
+      if (OUT_BF16) {
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)((short*)dpatch + ((long)b * N + (t - 1)) * D + d) = pk;
+      } else {
+        *(f32x4*)((float*)dpatch + ((long)b * N + (t - 1)) * D + d) = v;
+      }
     }
   }
   if (t == 0) {
@@ -96,7 +106,8 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, short* _
 }
 
 // ------------------------------------------------------------------------------------------ dropout bwd + cast
-__global__ void dropout_bwd_cast_kernel(const float* __restrict__ dx, short* __restrict__ dy, long rows, int cols,
+template <int OUT_BF16>
+__global__ void dropout_bwd_cast_kernel(const float* __restrict__ dx, void* __restrict__ dy, long rows, int cols,
                                         DropCfg drop) {
   const int cv = cols >> 2;
   const long total = rows * cv;
@@ -110,8 +121,12 @@ __global__ void dropout_bwd_cast_kernel(const float* __restrict__ dx, short* __r
       drop_pair(drop, (unsigned long long)row, (unsigned)(cols >> 1), (unsigned)c + 2, k2, k3);
       v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
     }
-    u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-    *(u32x2*)(dy + row * cols + c) = pk;
+    if (OUT_BF16) {
+      u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      *(u32x2*)((short*)dy + row * cols + c) = pk;
+    } else {
+      *(f32x4*)((float*)dy + row * cols + c) = v;
+    }
   }
 }
 
@@ -357,15 +372,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 extern "C" {
 using namespace vit;
 
-int vit_unfold_cast(vit_handle h, const float* x, void* patches, int B, int L, int P, int S, int N, vit_stream stream) {
+int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, int B, int L, int P, int S, int N,
+                    vit_stream stream) {
   (void)h;
   VIT_CHECK(x && patches, VIT_ERR_ARG, "vit_unfold_cast: null pointer");
   VIT_CHECK(B > 0 && L > 0 && P > 0 && S > 0 && N > 0 && (P % 4) == 0, VIT_ERR_ARG,
             "vit_unfold_cast: B=%d L=%d P=%d S=%d N=%d (P must be a multiple of 4)", B, L, P, S, N);
   VIT_CHECK((long)(N - 1) * S < L, VIT_ERR_ARG, "vit_unfold_cast: patch %d starts past the signal", N - 1);
   const long total = (long)B * N * (P / 4);
-  hipLaunchKernelGGL(unfold_cast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, (short*)patches, B,
-                     L, P, S, N);
+  if (out_dtype == VIT_BF16)
+    hipLaunchKernelGGL(unfold_cast_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, L, P, S, N);
+  else
+    hipLaunchKernelGGL(unfold_cast_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, L, P, S, N);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
@@ -383,25 +401,34 @@ int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float*
   return VIT_OK;
 }
 
-int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, float* dcls, float* dpos, int B, int T,
-                         int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate, vit_stream stream) {
+int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, int dpatch_dtype, float* dcls, float* dpos,
+                         int B, int T, int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate,
+                         vit_stream stream) {
   (void)h;
   VIT_CHECK(dtokens && dpatch_out && dcls, VIT_ERR_ARG, "vit_embed_finish_bwd: null pointer");
   VIT_CHECK(B > 0 && T > 1 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_embed_finish_bwd: B=%d T=%d D=%d", B, T, D);
-  hipLaunchKernelGGL(embed_finish_bwd_kernel, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                     dtokens, (short*)dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
+  if (dpatch_dtype == VIT_BF16)
+    hipLaunchKernelGGL(embed_finish_bwd_kernel<1>, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       dtokens, dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
+  else
+    hipLaunchKernelGGL(embed_finish_bwd_kernel<0>, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       dtokens, dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
 
-int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int rows, int cols, float dropout_p, uint64_t seed,
-                         uint64_t site, vit_stream stream) {
+int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int dy_dtype, int rows, int cols, float dropout_p,
+                         uint64_t seed, uint64_t site, vit_stream stream) {
   (void)h;
   VIT_CHECK(dx && dy, VIT_ERR_ARG, "vit_dropout_bwd_cast: null pointer");
   VIT_CHECK(rows > 0 && cols > 0 && (cols % 4) == 0, VIT_ERR_ARG, "vit_dropout_bwd_cast: rows=%d cols=%d", rows, cols);
   const long total = (long)rows * (cols / 4);
-  hipLaunchKernelGGL(dropout_bwd_cast_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, (short*)dy,
-                     (long)rows, cols, make_drop(dropout_p, seed, site));
+  if (dy_dtype == VIT_BF16)
+    hipLaunchKernelGGL(dropout_bwd_cast_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, dy,
+                       (long)rows, cols, make_drop(dropout_p, seed, site));
+  else
+    hipLaunchKernelGGL(dropout_bwd_cast_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, dy,
+                       (long)rows, cols, make_drop(dropout_p, seed, site));
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

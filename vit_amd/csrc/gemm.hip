@@ -47,6 +47,81 @@ struct GemmArgs {
 
 __device__ __forceinline__ int tr_swz(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
 
+// Epilogue shared by the bf16 and the split-bf16 ("x3") kernels: lane owns row m = .. + l15 and the 4 consecutive
+// columns n = .. + lg*4 + {0..3} of each 16x16 accumulator tile.  AUX_F32: the saved pre-activation is f32 (f32 mode).
+template <int AUX_F32>
+__device__ __forceinline__ void generic_epilogue(f32x4 (&acc)[4][4], const GemmArgs& p, int m0, int n0, int wm, int wn,
+                                                 int l15, int lg, int z, int batch) {
+  if (p.splits > 1) {
+    float* slab = p.slab + (long)z * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + lg * 4;
+        if (n < p.N) *(f32x4*)(slab + (long)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+  char* Cb = p.C + (long)batch * p.c_bs * (p.c_dtype == VIT_BF16 ? 2 : 4);
+  const unsigned half_cols = (unsigned)(p.N >> 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m >= p.M) continue;
+    long orow = m;
+    if (p.rpb > 0) {
+      const int b = m / p.rpb;
+      orow = (long)b * p.orb + (m - b * p.rpb) + p.roff;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j] * p.alpha;
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if (p.act == VIT_ACT_GELU) {
+        if (p.aux_out) {
+          if (AUX_F32) {
+            *(f32x4*)((float*)p.aux_out + orow * p.ldaux + n) = v;
+          } else {
+            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *(u32x2*)(p.aux_out + orow * p.ldaux + n) = pk;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == VIT_ACT_DGELU) {
+        if (AUX_F32) {
+          const f32x4 u = *(const f32x4*)((const float*)p.aux_in + orow * p.ldaux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(u[r]);
+        } else {
+          bf16x4 u = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
+        }
+      }
+      if (p.drop.thr) {
+        float k0, k1, k2, k3;
+        drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n, k0, k1);
+        drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n + 2, k2, k3);
+        v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
+      }
+      if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldres + n);
+      if (p.c_dtype == VIT_BF16) {
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)(Cb + (orow * p.ldc + n) * 2) = pk;
+      } else {
+        *(f32x4*)(Cb + (orow * p.ldc + n) * 4) = v;
+      }
+    }
+  }
+}
+
 template <int TRANS>
 struct Loader {
   // per-thread addressing of one operand tile: 4 x 16-byte global loads and 4 x ds_write_b128
@@ -207,65 +282,151 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_bf16_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m = .. + l15 and the 4 consecutive columns n = .. + lg*4 + {0..3}
-  if (p.splits > 1) {
-    float* slab = p.slab + (long)z * p.M * p.N;
+  generic_epilogue<0>(acc, p, m0, n0, wm, wn, l15, lg, z, batch);
+}
+
+// ------------------------------------------------------------------------------------------------ f32 operands ("x3")
+// fp32-class GEMM on the bf16 matrix cores: every f32 operand element x is split on its way into the LDS into
+// hi = bf16(x) and lo = bf16(x - hi) (two images per operand), and each fragment pair issues three MFMAs,
+// acc += Ahi*Bhi + Ahi*Blo + Alo*Bhi  (the lo*lo term is below 2^-16 relative).  Operands keep ~16 mantissa bits and
+// accumulation is fp32, so results agree with an fp32 GEMM to ~1e-5 relative: this is the arithmetic behind
+// precision='32' (the reference's default, basemodule.py:233).  Tile 128x128x32, same images / fragment maps / epilogue
+// as the bf16 kernel.
+constexpr int XBK = 32;
+constexpr int XIMG = 128 * XBK * 2;          // one bf16 image of one operand: 8 KiB
+constexpr int XSTAGE = 4 * XIMG;             // A_hi, A_lo, B_hi, B_lo
+
+// 8 consecutive f32 (two 16-byte vectors) -> one bf16x8 chunk of the "hi" image and one of the "lo" image
+__device__ __forceinline__ void split8(const i32x4& v0, const i32x4& v1, i32x4& out_hi, i32x4& out_lo) {
+  const f32x4 a = __builtin_bit_cast(f32x4, v0), b = __builtin_bit_cast(f32x4, v1);
+  const unsigned h0 = pack2bf(a[0], a[1]), h1 = pack2bf(a[2], a[3]), h2 = pack2bf(b[0], b[1]), h3 = pack2bf(b[2], b[3]);
+  const f32x4 ra = {a[0] - __builtin_bit_cast(float, h0 << 16), a[1] - __builtin_bit_cast(float, h0 & 0xFFFF0000u),
+                    a[2] - __builtin_bit_cast(float, h1 << 16), a[3] - __builtin_bit_cast(float, h1 & 0xFFFF0000u)};
+  const f32x4 rb = {b[0] - __builtin_bit_cast(float, h2 << 16), b[1] - __builtin_bit_cast(float, h2 & 0xFFFF0000u),
+                    b[2] - __builtin_bit_cast(float, h3 << 16), b[3] - __builtin_bit_cast(float, h3 & 0xFFFF0000u)};
+  out_hi = (i32x4){(int)h0, (int)h1, (int)h2, (int)h3};
+  out_lo = (i32x4){(int)pack2bf(ra[0], ra[1]), (int)pack2bf(ra[2], ra[3]), (int)pack2bf(rb[0], rb[1]),
+                   (int)pack2bf(rb[2], rb[3])};
+}
+
+template <int A_T, int B_T>
+__global__ __launch_bounds__(NTHR, 2) void gemm_f32x3_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * XSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int batch = z / p.splits, split = z - batch * p.splits;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int klen = k_end - k_begin;
+  const int nk = (klen + XBK - 1) / XBK;
+
+  const char* Ab;
+  const char* Bb;
+  unsigned long long a_bytes, b_bytes;
+  if (A_T == 0) { Ab = p.A + ((long)batch * p.a_bs + (long)m0 * p.lda + k_begin) * 4; a_bytes = (unsigned long long)(p.M - m0) * p.lda * 4; }
+  else { Ab = p.A + ((long)batch * p.a_bs + (long)k_begin * p.lda + m0) * 4; a_bytes = (unsigned long long)klen * p.lda * 4; }
+  if (B_T == 0) { Bb = p.B + ((long)batch * p.b_bs + (long)n0 * p.ldb + k_begin) * 4; b_bytes = (unsigned long long)(p.N - n0) * p.ldb * 4; }
+  else { Bb = p.B + ((long)batch * p.b_bs + (long)k_begin * p.ldb + n0) * 4; b_bytes = (unsigned long long)klen * p.ldb * 4; }
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(Ab, a_bytes);
+  const __amdgpu_buffer_rsrc_t rb = make_rsrc(Bb, b_bytes);
+
+  // per-thread: 2 bf16 chunks (8 elements = 32 bytes of f32) per operand per K-tile
+  unsigned voffA[2], voffB[2], ldsA[2], ldsB[2];
+  bool okA[2], okB[2];
+  int kcA[2], kcB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + NTHR * i;
+    if (A_T == 0) { const int r = q >> 2, c = q & 3; voffA[i] = (unsigned)(r * p.lda * 4 + c * 32); ldsA[i] = r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4); kcA[i] = c * 8; okA[i] = true; }
+    else { const int kr = q >> 4, c16 = q & 15; voffA[i] = (unsigned)(kr * p.lda * 4 + c16 * 32); ldsA[i] = kr * 256 + (((2 * c16) ^ tr_swz(kr)) << 3); kcA[i] = 0; okA[i] = (c16 * 8) < (p.M - m0); }
+    if (B_T == 0) { const int r = q >> 2, c = q & 3; voffB[i] = (unsigned)(r * p.ldb * 4 + c * 32); ldsB[i] = r * 64 + ((c ^ ((-(r >> 2)) & 3)) << 4); kcB[i] = c * 8; okB[i] = true; }
+    else { const int kr = q >> 4, c16 = q & 15; voffB[i] = (unsigned)(kr * p.ldb * 4 + c16 * 32); ldsB[i] = kr * 256 + (((2 * c16) ^ tr_swz(kr)) << 3); kcB[i] = 0; okB[i] = (c16 * 8) < (p.N - n0); }
+  }
+  const unsigned a_step = (A_T == 0) ? XBK * 4 : (unsigned)(XBK * p.lda * 4);
+  const unsigned b_step = (B_T == 0) ? XBK * 4 : (unsigned)(XBK * p.ldb * 4);
+
+  i32x4 sa[2][2], sb[2][2];
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (A_T == 0) ? (kt * XBK + kcA[i] < klen) : okA[i];
+      const unsigned vo = ok ? voffA[i] + (unsigned)kt * a_step : OOB;
+      sa[i][0] = __builtin_amdgcn_raw_buffer_load_b128(ra, vo, 0, 0);
+      sa[i][1] = __builtin_amdgcn_raw_buffer_load_b128(ra, ok ? vo + 16 : OOB, 0, 0);
+      const bool okb = (B_T == 0) ? (kt * XBK + kcB[i] < klen) : okB[i];
+      const unsigned vb = okb ? voffB[i] + (unsigned)kt * b_step : OOB;
+      sb[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rb, vb, 0, 0);
+      sb[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rb, okb ? vb + 16 : OOB, 0, 0);
+    }
+  };
+  auto commit = [&](int stage) {
+    char* st = smem + stage * XSTAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      i32x4 h, l;
+      split8(sa[i][0], sa[i][1], h, l);
+      *(i32x4*)(st + ldsA[i]) = h;
+      *(i32x4*)(st + XIMG + ldsA[i]) = l;
+      split8(sb[i][0], sb[i][1], h, l);
+      *(i32x4*)(st + 2 * XIMG + ldsB[i]) = h;
+      *(i32x4*)(st + 3 * XIMG + ldsB[i]) = l;
+    }
+  };
+
+  const int kc_off = l15 * 64 + ((lg ^ ((-(l15 >> 2)) & 3)) << 4);
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int tr_f = (tq | ((lg & 1) << 2)) << 2;
+  auto read_frag = [&](const char* img, int trans, int base16) -> bf16x8 {
+    if (!trans) {
+      return *(const bf16x8*)(img + base16 * 64 + kc_off);
+    } else {
+      const char* pa = img + (lg * 8 + tq) * 256 + ((((base16 >> 2) + tp) ^ tr_f) << 3);
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * 256));
+      return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    issue(0);
+    commit(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* st = smem + cur * XSTAGE;
+    bf16x8 ah[4], al[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + l15;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + lg * 4;
-        if (n < p.N) *(f32x4*)(slab + (long)m * p.N + n) = acc[i][j];
-      }
-    }
-    return;
-  }
-  char* Cb = p.C + (long)batch * p.c_bs * (p.c_dtype == VIT_BF16 ? 2 : 4);
-  const unsigned half_cols = (unsigned)(p.N >> 1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= p.M) continue;
-    long orow = m;
-    if (p.rpb > 0) {
-      const int b = m / p.rpb;
-      orow = (long)b * p.orb + (m - b * p.rpb) + p.roff;
+      ah[i] = read_frag(st, A_T, wm * 64 + i * 16);
+      al[i] = read_frag(st + XIMG, A_T, wm * 64 + i * 16);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j] * p.alpha;
-      if (p.bias) v += *(const f32x4*)(p.bias + n);
-      if (p.act == VIT_ACT_GELU) {
-        if (p.aux_out) {
-          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(u32x2*)(p.aux_out + orow * p.ldaux + n) = pk;
-        }
+      const bf16x8 bh = read_frag(st + 2 * XIMG, B_T, wn * 64 + j * 16);
+      const bf16x8 bl = read_frag(st + 3 * XIMG, B_T, wn * 64 + j * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == VIT_ACT_DGELU) {
-        bf16x4 u = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
-      }
-      if (p.drop.thr) {
-        float k0, k1, k2, k3;
-        drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n, k0, k1);
-        drop_pair(p.drop, (unsigned long long)orow, half_cols, (unsigned)n + 2, k2, k3);
-        v[0] *= k0; v[1] *= k1; v[2] *= k2; v[3] *= k3;
-      }
-      if (p.residual) v += *(const f32x4*)(p.residual + orow * p.ldres + n);
-      if (p.c_dtype == VIT_BF16) {
-        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *(u32x2*)(Cb + (orow * p.ldc + n) * 2) = pk;
-      } else {
-        *(f32x4*)(Cb + (orow * p.ldc + n) * 4) = v;
+      for (int i = 0; i < 4; ++i) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
       }
     }
+    if (kt + 1 < nk) commit(cur ^ 1);
+    __syncthreads();
   }
+  generic_epilogue<1>(acc, p, m0, n0, wm, wn, l15, lg, z, batch);
 }
 
 // C (f32) (+)= alpha * sum over split slabs; one float4 per thread
@@ -303,7 +464,8 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   VIT_CHECK(d && d->A && d->B && d->C, VIT_ERR_ARG, "vit_gemm: null operand");
   VIT_CHECK(d->M > 0 && d->N > 0 && d->K > 0, VIT_ERR_ARG, "vit_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
-  VIT_CHECK(d->ab_dtype == VIT_BF16, VIT_ERR_UNSUPPORTED, "vit_gemm: only bf16 operands are implemented");
+  VIT_CHECK(d->ab_dtype == VIT_BF16 || d->ab_dtype == VIT_F32, VIT_ERR_ARG, "vit_gemm: bad ab_dtype");
+  const bool f32in = d->ab_dtype == VIT_F32;
   VIT_CHECK(d->c_dtype == VIT_BF16 || d->c_dtype == VIT_F32, VIT_ERR_ARG, "vit_gemm: bad c_dtype");
   // 16-byte vectors along each operand's contiguous dimension: K for a K-contiguous operand, M / N for a transposed one
   // (whose K is a row index, bounded by the buffer resource, so any K works there: dW sums over B*T tokens).
@@ -324,7 +486,7 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   VIT_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f, VIT_ERR_ARG, "vit_gemm: dropout_p out of [0,1)");
 
   if (d->dropout_p > 0.f) VIT_CHECK((d->N % 2) == 0, VIT_ERR_ARG, "vit_gemm: dropout needs an even N");
-  {
+  if (!f32in) {
     int rc2 = VIT_OK;  // tile-aligned problems go to the LDS-DMA / persistent core
     if (gemm2_try_launch(h, d, st, &rc2)) return rc2;
   }
@@ -335,7 +497,8 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   a.a_bs = a.b_bs = a.c_bs = 0;
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.tiles_m = cdiv(d->M, BM); a.tiles_n = cdiv(d->N, BN);
-  const int ktiles = cdiv(d->K, BK);
+  const int bk = f32in ? XBK : BK;
+  const int ktiles = cdiv(d->K, bk);
   int splits = d->split_k;
   if (splits < 0) {
     const int tiles = a.tiles_m * a.tiles_n;
@@ -344,7 +507,7 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   }
   if (splits < 1) splits = 1;
   if (splits > ktiles) splits = ktiles;
-  int kps = cdiv(ktiles, splits) * BK;
+  int kps = cdiv(ktiles, splits) * bk;
   splits = cdiv(d->K, kps);
   a.splits = splits; a.k_per_split = kps;
   a.slab = nullptr;
@@ -374,7 +537,16 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
 
   dim3 grid(a.tiles_m * a.tiles_n, splits), block(NTHR);
   const int v = d->a_trans * 2 + d->b_trans;
-  snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm_bf16_kernel<%d, %d>", d->a_trans, d->b_trans);
+  snprintf(g_last_gemm, sizeof(g_last_gemm), "%s<%d, %d>", f32in ? "gemm_f32x3_kernel" : "gemm_bf16_kernel", d->a_trans,
+           d->b_trans);
+  if (f32in) {
+    switch (v) {
+      case 0: hipLaunchKernelGGL((gemm_f32x3_kernel<0, 0>), grid, block, 0, st, a); break;
+      case 1: hipLaunchKernelGGL((gemm_f32x3_kernel<0, 1>), grid, block, 0, st, a); break;
+      case 2: hipLaunchKernelGGL((gemm_f32x3_kernel<1, 0>), grid, block, 0, st, a); break;
+      default: hipLaunchKernelGGL((gemm_f32x3_kernel<1, 1>), grid, block, 0, st, a); break;
+    }
+  } else
   switch (v) {
     case 0: hipLaunchKernelGGL((gemm_bf16_kernel<0, 0>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((gemm_bf16_kernel<0, 1>), grid, block, 0, st, a); break;

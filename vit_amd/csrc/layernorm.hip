@@ -70,12 +70,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // FUSE: additionally emit dyn = dropout_mask(drop) * dx as bf16 (the gradient wrt the Linear output that sits under the
 // "dropout(.) + residual" this LayerNorm's input came from) and its column sums (that Linear's bias gradient) as a
 // third partial row -- what vit_dropout_bwd_cast + vit_colsum would otherwise re-read dx for.
+// FUSE: 0 = plain, 1 = + bf16 dyn, 2 = + f32 dyn
 template <int NV, int DY_BF16, int FUSE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part, int rows, int D,
-                                                     short* __restrict__ dyn, DropCfg drop) {
+                                                     void* __restrict__ dyn, DropCfg drop) {
   constexpr int NP = FUSE ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][D]
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -133,11 +134,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
             drop_pair(drop, (unsigned long long)row, (unsigned)(D >> 1), (unsigned)(4 * c) + 2, k2, k3);
             o[0] *= k0; o[1] *= k1; o[2] *= k2; o[3] *= k3;
           }
-          u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-          *(u32x2*)(dyn + (long)row * D + 4 * c) = pk;
-          // sum what was stored (bf16-rounded), exactly like colsum over the bf16 tensor would
-          dbias[i] += (f32x4){bf2f((short)(pk[0] & 0xFFFF)), bf2f((short)(pk[0] >> 16)), bf2f((short)(pk[1] & 0xFFFF)),
-                              bf2f((short)(pk[1] >> 16))};
+          if (FUSE == 1) {
+            u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            *(u32x2*)((short*)dyn + (long)row * D + 4 * c) = pk;
+            // sum what was stored (bf16-rounded), exactly like colsum over the bf16 tensor would
+            dbias[i] += (f32x4){bf2f((short)(pk[0] & 0xFFFF)), bf2f((short)(pk[0] >> 16)), bf2f((short)(pk[1] & 0xFFFF)),
+                                bf2f((short)(pk[1] >> 16))};
+          } else {
+            *(f32x4*)((float*)dyn + (long)row * D + 4 * c) = o;
+            dbias[i] += o;
+          }
         }
       }
     }
@@ -180,10 +186,11 @@ static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void*
 
 template <int DY_BF16, int FUSE>
 static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const float* mean, const float* rstd,
-                           const float* dres, float* dx, float* part, int rows, int D, int blocks, short* dyn,
+                           const float* dres, float* dx, float* part, int rows, int D, int blocks, void* dyn,
                            DropCfg drop, hipStream_t st) {
   const int nv = cdiv(D, 256);
   const size_t sh = (size_t)4 * (FUSE ? 3 : 2) * D * sizeof(float);
+  if (sh > 64 * 1024) { set_error("vit_layernorm_bwd: D=%d needs %zu bytes of LDS", D, sh); return VIT_ERR_UNSUPPORTED; }
 #define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16, FUSE>), dim3(blocks), dim3(256), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D, dyn, drop)
   if (nv <= 1) LAUNCH(1);
   else if (nv <= 2) LAUNCH(2);
@@ -198,7 +205,8 @@ static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const
 
 static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
                          const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
-                         float* dbeta, int rows, int D, short* dyn, float* dbias, DropCfg drop, hipStream_t st) {
+                         float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, DropCfg drop,
+                         hipStream_t st) {
   const int blocks = std::min(cdiv(rows, 16), 512);
   const int np = dyn ? 3 : 2;
   size_t wsb = 0;
@@ -206,8 +214,12 @@ static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float
   const size_t need = (size_t)blocks * np * D * sizeof(float);
   VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_layernorm_bwd: needs %zu workspace bytes, have %zu", need, wsb);
   int rc;
-  if (dyn) rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
-                                     : ln_bwd_dispatch<0, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+  if (dyn && dyn_dtype == VIT_BF16)
+    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
+                              : ln_bwd_dispatch<0, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+  else if (dyn)
+    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
+                              : ln_bwd_dispatch<0, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
   else rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
                                  : ln_bwd_dispatch<0, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
   if (rc != VIT_OK) return rc;
@@ -238,20 +250,20 @@ int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x
   using namespace vit;
   VIT_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, VIT_ERR_ARG, "vit_layernorm_bwd: null pointer");
   VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd: rows=%d D=%d", rows, D);
-  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, nullptr,
+  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, nullptr, VIT_BF16, nullptr,
                        make_drop(0.f, 0, 0), (hipStream_t)stream);
 }
 
 int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,
                             const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
-                            float* dbeta, int rows, int D, void* dyn, float* dbias, float dropout_p, uint64_t seed,
-                            uint64_t site, vit_stream stream) {
+                            float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, float dropout_p,
+                            uint64_t seed, uint64_t site, vit_stream stream) {
   using namespace vit;
   VIT_CHECK(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && dyn && dbias, VIT_ERR_ARG,
             "vit_layernorm_bwd_fused: null pointer");
   VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd_fused: rows=%d D=%d", rows, D);
   VIT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, VIT_ERR_ARG, "vit_layernorm_bwd_fused: dropout_p out of [0,1)");
-  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, (short*)dyn, dbias,
+  return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, dyn, dyn_dtype, dbias,
                        make_drop(dropout_p, seed, site), (hipStream_t)stream);
 }
 

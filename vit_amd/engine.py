@@ -144,6 +144,7 @@ class ViTEngine:
         self._arena_key = None
         self.act: Dict[str, object] = {}
         self.tmp: Dict[str, torch.Tensor] = {}
+        self.precision = "f32"       # 'f32' (reference default precision='32') | 'bf16' (precision='bf16-mixed')
         self.base_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self.step_counter = 0
         self._last = None
@@ -152,6 +153,31 @@ class ViTEngine:
         # the base's), so "were the f32 weights modified since the bf16 shadow was made?" is answered by a signature
         # over the parameters' versions, supplied by the owning module.
         self.version_fn: Callable[[], int] = lambda: self.flat._version
+
+    # ------------------------------------------------------------------ precision
+    def set_precision(self, precision) -> str:
+        """Lightning-style precision strings (basemodule.py:233: `precision=str(train.precision or '32')`).
+        '32' -> fp32-class arithmetic: f32 activations, split-bf16 ("x3") MFMA GEMMs, fp32 attention / LayerNorm.
+        'bf16-mixed' -> bf16 MFMA operands with fp32 accumulation, residual stream and statistics (the fast path)."""
+        ps = str(precision).lower()
+        if ps in ("32", "32-true", "fp32", "f32", "float32"):
+            mode = "f32"
+        elif ps in ("bf16-mixed", "bf16", "bf16-true", "bfloat16"):
+            mode = "bf16"
+        elif ps in ("16-mixed", "16", "16-true", "fp16"):
+            print("[vit_amd] fp16 precision is not implemented on this path; using bf16-mixed arithmetic instead")
+            mode = "bf16"
+        else:
+            raise ValueError(f"Unsupported precision '{precision}'")
+        if mode != self.precision:
+            self.precision = mode
+            self._arena_key = None
+            self.act, self.tmp = {}, {}
+        return mode
+
+    @property
+    def adt(self):
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
     # ------------------------------------------------------------------ parameters
     @property
@@ -176,9 +202,12 @@ class ViTEngine:
         if not self.flat.is_cuda:
             raise VitError("vit_amd runs on an MI355X only: move the model to the GPU first (model.to('cuda')); "
                            "there is no CPU fallback path")
+        if self.grads is None:
+            self.grads = torch.zeros(self.layout.n_total, dtype=torch.float32, device=self.flat.device)
+        if self.precision != "bf16":
+            return  # the x3 GEMMs read the f32 master weights directly
         if self.shadow is None:
             self.shadow = torch.empty(self.layout.n_total, dtype=torch.bfloat16, device=self.flat.device)
-            self.grads = torch.zeros(self.layout.n_total, dtype=torch.float32, device=self.flat.device)
             self._shadow_version = -1
         ver = self.version_fn()
         if self._shadow_version != ver:
@@ -189,7 +218,8 @@ class ViTEngine:
         self._shadow_version = self.version_fn()
 
     def w16(self, name: str) -> torch.Tensor:
-        return self.layout.view(self.shadow, name)
+        """GEMM weight operand: bf16 shadow view, or the f32 master view in f32 mode."""
+        return self.layout.view(self.shadow if self.precision == "bf16" else self.flat, name)
 
     def g(self, name: str) -> torch.Tensor:
         return self.layout.view(self.grads, name)
@@ -197,7 +227,8 @@ class ViTEngine:
     def _qkv16(self, i: int):
         off, _ = self.layout.entries[f"vit.encoder.layer.{i}.attention.attention.query.weight"]
         D = self.cfg.hidden_size
-        return self.shadow[off:off + 3 * D * D].view(3 * D, D)
+        src = self.shadow if self.precision == "bf16" else self.flat
+        return src[off:off + 3 * D * D].view(3 * D, D)
 
     def _qkv_bias(self, i: int, buf: torch.Tensor):
         off, _ = self.layout.entries[f"vit.encoder.layer.{i}.attention.attention.query.bias"]
@@ -211,7 +242,7 @@ class ViTEngine:
 
     # ------------------------------------------------------------------ arena
     def _ensure_arena(self, B: int, train: bool):
-        key = (B, train)
+        key = (B, train, self.precision)
         if self._arena_key == key:
             return
         c = self.cfg
@@ -220,7 +251,7 @@ class ViTEngine:
             c.num_hidden_layers, c.num_patches, c.patch_size
         M = B * T
         nl = L if train else 1
-        f32, b16 = torch.float32, torch.bfloat16
+        f32, b16 = torch.float32, self.adt  # "b16" = the activation/operand dtype of the current precision mode
 
         def E(shape, dt):
             return torch.empty(shape, dtype=dt, device=dev)
@@ -274,7 +305,7 @@ class ViTEngine:
         e = "vit.embeddings."
 
         # --- embeddings: unfold -> projection (+bias) into token rows 1..N -> CLS / pos-emb / dropout
-        vf.unfold_cast(x, P, S, N, out=a["patches"])
+        vf.unfold_cast(x, P, S, N, out=a["patches"])  # bf16 or f32 patches, per the arena dtype
         wp = self.w16(e + "patch_embeddings.projection.weight").view(D, P)
         x0 = a["x"][0]
         vf.gemm(a["patches"], wp, M=B * N, N=D, K=P, out=x0.view(M, D), bias=self.p(e + "patch_embeddings.projection.bias"),
@@ -390,7 +421,7 @@ class ViTEngine:
         e = "vit.embeddings."
         dpos = self.g(e + "position_embeddings").view(T, D) if c.pos_encoding_type == "learned" else None
         vf.embed_finish_bwd(dx.view(B, T, D), self.g(e + "cls_token").view(D), dpos, dropout=(ph, seed, 0),
-                            dpatch=t["dpatch"])
+                            dpatch=t["dpatch"])  # dtype follows the buffer
         vf.colsum(t["dpatch"], out=self.g(e + "patch_embeddings.projection.bias"))
         vf.gemm(t["dpatch"], a["patches"], M=D, N=P, K=B * N, a_trans=True, b_trans=True,
                 out=self.g(e + "patch_embeddings.projection.weight").view(D, P), split_k=-1)

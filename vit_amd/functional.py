@@ -46,14 +46,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
          dropout: Dropout = NO_DROP, residual: Optional[torch.Tensor] = None, row_map: Tuple[int, int, int] = (0, 0, 0),
          out_rows: Optional[int] = None, split_k: int = 0, accumulate: bool = False) -> torch.Tensor:
     h = _h(a)
-    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16:
-        raise _cabi.VitError("gemm: operands must be bf16")
+    if a.dtype != b.dtype or a.dtype not in _DT:
+        raise _cabi.VitError(f"gemm: operands must both be bf16 or both f32 (got {a.dtype}, {b.dtype})")
     if out is None:
         out = torch.empty((out_rows if out_rows is not None else M, N), dtype=out_dtype, device=a.device)
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.a_trans, d.b_trans = int(a_trans), int(b_trans)
-    d.ab_dtype = VIT_BF16
+    d.ab_dtype = _DT[a.dtype]  # f32 operands: split-bf16 "x3" kernel (fp32-class results)
     d.A, d.lda = a.data_ptr(), lda if lda is not None else (M if a_trans else K)
     d.B, d.ldb = b.data_ptr(), ldb if ldb is not None else (N if b_trans else K)
     d.C, d.ldc, d.c_dtype = out.data_ptr(), ldc if ldc is not None else N, _DT[out.dtype]
@@ -138,52 +138,51 @@ def layernorm_bwd_fused(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dyn, 
     p, seed, site = dropout
     check(h.lib.vit_layernorm_bwd_fused(h.h, dy.data_ptr(), _DT[dy.dtype], x.data_ptr(), gamma.data_ptr(),
                                         mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(), dgamma.data_ptr(),
-                                        dbeta.data_ptr(), rows, D, dyn.data_ptr(), dbias.data_ptr(), p, seed, site,
-                                        _stream(x)), "vit_layernorm_bwd_fused")
+                                        dbeta.data_ptr(), rows, D, dyn.data_ptr(), _DT[dyn.dtype], dbias.data_ptr(), p, seed,
+                                        site, _stream(x)), "vit_layernorm_bwd_fused")
     return dx, dgamma, dbeta, dyn, dbias
 
 
 # ------------------------------------------------------------------------------------------------ attention
 def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP, ctx=None, lse=None):
-    _chk(qkv, torch.bfloat16, "attention_fwd qkv")
     h = _h(qkv)
-    ctx = ctx if ctx is not None else torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=qkv.device)
+    ctx = ctx if ctx is not None else torch.empty((B * T, H * dh), dtype=qkv.dtype, device=qkv.device)
     lse = lse if lse is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
     p, seed, site = dropout
-    check(h.lib.vit_attention_fwd(h.h, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, H, T, dh, scale, p, seed, site,
-                                  _stream(qkv)), "vit_attention_fwd")
+    check(h.lib.vit_attention_fwd(h.h, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale,
+                                  p, seed, site, _stream(qkv)), "vit_attention_fwd")
     return ctx, lse
 
 
 def attention_bwd(qkv, ctx, dctx, lse, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP,
                   dqkv=None, delta=None):
-    _chk(qkv, torch.bfloat16, "attention_bwd qkv")
-    _chk(dctx, torch.bfloat16, "attention_bwd dctx")
+    _chk(dctx, qkv.dtype, "attention_bwd dctx")
     h = _h(qkv)
     dqkv = dqkv if dqkv is not None else torch.empty_like(qkv)
     delta = delta if delta is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
     p, seed, site = dropout
     check(h.lib.vit_attention_bwd(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                  dqkv.data_ptr(), B, H, T, dh, scale, p, seed, site, _stream(qkv)), "vit_attention_bwd")
+                                  dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed, site, _stream(qkv)),
+          "vit_attention_bwd")
     return dqkv
 
 
 def attention_probs(qkv, B: int, H: int, T: int, dh: int, scale: float):
-    _chk(qkv, torch.bfloat16, "attention_probs qkv")
     h = _h(qkv)
     probs = torch.empty((B, H, T, T), dtype=torch.float32, device=qkv.device)
-    check(h.lib.vit_attention_probs(h.h, qkv.data_ptr(), probs.data_ptr(), B, H, T, dh, scale, _stream(qkv)),
-          "vit_attention_probs")
+    check(h.lib.vit_attention_probs(h.h, qkv.data_ptr(), probs.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale,
+                                    _stream(qkv)), "vit_attention_probs")
     return probs
 
 
 # ------------------------------------------------------------------------------------------------ embedding side
-def unfold_cast(x, P: int, S: int, N: int, out=None):
+def unfold_cast(x, P: int, S: int, N: int, out=None, out_dtype=torch.bfloat16):
     _chk(x, torch.float32, "unfold_cast x")
     h = _h(x)
     B, L = x.shape
-    out = out if out is not None else torch.empty((B * N, P), dtype=torch.bfloat16, device=x.device)
-    check(h.lib.vit_unfold_cast(h.h, x.data_ptr(), out.data_ptr(), B, L, P, S, N, _stream(x)), "vit_unfold_cast")
+    out = out if out is not None else torch.empty((B * N, P), dtype=out_dtype, device=x.device)
+    check(h.lib.vit_unfold_cast(h.h, x.data_ptr(), out.data_ptr(), _DT[out.dtype], B, L, P, S, N, _stream(x)),
+          "vit_unfold_cast")
     return out
 
 
@@ -197,27 +196,27 @@ def embed_finish(tokens, cls, pos=None, dropout: Dropout = NO_DROP):
     return tokens
 
 
-def embed_finish_bwd(dtokens, dcls, dpos=None, dropout: Dropout = NO_DROP, dpatch=None):
+def embed_finish_bwd(dtokens, dcls, dpos=None, dropout: Dropout = NO_DROP, dpatch=None, out_dtype=torch.bfloat16):
     _chk(dtokens, torch.float32, "embed_finish_bwd dtokens")
     h = _h(dtokens)
     B, T, D = dtokens.shape
-    dpatch = dpatch if dpatch is not None else torch.empty((B * (T - 1), D), dtype=torch.bfloat16, device=dtokens.device)
+    dpatch = dpatch if dpatch is not None else torch.empty((B * (T - 1), D), dtype=out_dtype, device=dtokens.device)
     p, seed, site = dropout
-    check(h.lib.vit_embed_finish_bwd(h.h, dtokens.data_ptr(), dpatch.data_ptr(), dcls.data_ptr(), _ptr(dpos), B, T, D, p,
-                                     seed, site, 0, _stream(dtokens)), "vit_embed_finish_bwd")
+    check(h.lib.vit_embed_finish_bwd(h.h, dtokens.data_ptr(), dpatch.data_ptr(), _DT[dpatch.dtype], dcls.data_ptr(),
+                                     _ptr(dpos), B, T, D, p, seed, site, 0, _stream(dtokens)), "vit_embed_finish_bwd")
     return dpatch
 
 
 # ------------------------------------------------------------------------------------------------ elementwise
-def dropout_bwd_cast(dx, dropout: Dropout = NO_DROP, out=None):
+def dropout_bwd_cast(dx, dropout: Dropout = NO_DROP, out=None, out_dtype=torch.bfloat16):
     _chk(dx, torch.float32, "dropout_bwd_cast dx")
     h = _h(dx)
     cols = dx.shape[-1]
     rows = dx.numel() // cols
-    out = out if out is not None else torch.empty(dx.shape, dtype=torch.bfloat16, device=dx.device)
+    out = out if out is not None else torch.empty(dx.shape, dtype=out_dtype, device=dx.device)
     p, seed, site = dropout
-    check(h.lib.vit_dropout_bwd_cast(h.h, dx.data_ptr(), out.data_ptr(), rows, cols, p, seed, site, _stream(dx)),
-          "vit_dropout_bwd_cast")
+    check(h.lib.vit_dropout_bwd_cast(h.h, dx.data_ptr(), out.data_ptr(), _DT[out.dtype], rows, cols, p, seed, site,
+                                     _stream(dx)), "vit_dropout_bwd_cast")
     return out
 
 

@@ -70,7 +70,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._clip is not None:
             sq = vf.grad_sqnorm(eng.grads[:n], out=self._sq)
             self.last_grad_norm = sq
-        vf.adamw_step(eng.flat, eng.grads, self._m, self._v, eng.shadow, lr=float(g["lr"]), beta1=g["betas"][0],
+        shadow = eng.shadow if eng.precision == "bf16" else None  # f32 mode has no bf16 copy to refresh
+        vf.adamw_step(eng.flat, eng.grads, self._m, self._v, shadow, lr=float(g["lr"]), beta1=g["betas"][0],
                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step, sqnorm=sq,
                       max_norm=float(self._clip or 0.0), n=n)
         eng.mark_shadow_fresh()  # the kernel rewrote flat AND shadow through raw pointers

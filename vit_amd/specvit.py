@@ -209,6 +209,10 @@ class MyViT(nn.Module):
         if self.preprocessor is None:
             return
 
+    def set_precision(self, precision) -> str:
+        """'32' (reference default; fp32-class kernels) or 'bf16-mixed' (bf16 MFMA operands): see ViTEngine."""
+        return self.engine.set_precision(precision)
+
     # ------------------------------------------------------------------ extras used by the build's own trainer
     def flat_parameters(self) -> torch.Tensor:
         return self.engine.flat

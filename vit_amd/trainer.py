@@ -7,8 +7,8 @@
   ReduceLROnPlateau on `val_{monitor}` / epoch- or step-interval schedulers (opt/optimizer.py:150-172);
   EarlyStopping(patience 500, vit.py:365,417-424); `fast_dev_run` when `train.debug` (basemodule.py:245).
 
-precision: 'bf16-mixed' arithmetic (bf16 MFMA operands, fp32 master weights / residual stream / statistics) is the only
-mode the kernels implement; `train.precision: 32` is accepted and noted.
+'train.precision': '32' (default, as in the reference) -> fp32-class kernels (split-bf16 x3 GEMMs, fp32 attention);
+'bf16-mixed' -> bf16 MFMA operands with fp32 master weights / residual stream / statistics (the throughput path).
 """
 from __future__ import annotations
 
@@ -88,6 +88,8 @@ class Trainer:
     def _setup(self, module):
         module.trainer = self
         module.to(self.device)
+        if hasattr(module.model, "set_precision"):
+            module.model.set_precision(self.precision)  # basemodule.py:233: precision=str(train.precision or '32')
         conf = module.configure_optimizers()
         if isinstance(conf, dict):
             self.optimizer = conf["optimizer"]
