@@ -174,9 +174,18 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12
         gemm_ms = sum(v[1] for v in agg.values())
         gemm_fl = sum(v[2] for v in agg.values())
+        traffic = None  # HBM bytes per launch of that kernel, from the committed PMC passes (profiles/*pmc_traffic.json)
+        try:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
+                ent = json.load(open(path))["kernels"].get(var)
+                if ent and args.workload == "vit_b16_224" and B == 256:
+                    traffic = ent["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001 - the profile summary is optional evidence, never required to run
+            traffic = None
         roofline = {
             "bound": "mfma", "kernel": var, "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12,
-            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
             "flop_per_launch": fl / n, "mean_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
             "share_of_step_time": round(ms / (dt * 1e3), 3),
             "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
