@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""`scripts/run.py` of the reference (scripts/run.py:14-54) on the MI355X path: same arguments (-f/--config, -w, --save,
+-g, --debug, --ckpt, --seed), same seeding and config plumbing, `Experiment(...).run()` replaced by the build's module +
+trainer.  The reference's HDF5 datasets are out of scope, so data comes from `--synthetic N`
+seeded spectra with the reference's batch contract (flux, error, labels)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+
+from vit_amd.module import ViTLModule
+from vit_amd.trainer import Trainer, seed_everything
+from vit_amd.utils import load_config
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="ViT experiment runner (MI355X path)")
+    p.add_argument("-f", "--config", type=str, default="configs/baseline.yaml")
+    p.add_argument("-w", "--wandb", type=int, default=0, help="accepted for CLI compatibility; W&B is out of scope")
+    p.add_argument("--save", action="store_true")
+    p.add_argument("-g", "--gpu", type=int, default=None)
+    p.add_argument("--debug", type=int, default=0)
+    p.add_argument("--ckpt", type=str, default=None)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--synthetic", type=int, default=4096, help="number of synthetic training spectra")
+    return p.parse_args()
+
+
+class SyntheticSpectra:
+    """Seeded (flux, error, labels) batches: make_dummy_spectra-like absorption lines (src/utils.py:131-139) whose depth
+    encodes the label, so the loss has something to learn."""
+
+    def __init__(self, n, length, batch_size, task, num_labels, seed, shuffle):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.arange(length)
+        self.labels = torch.rand(n, generator=g)
+        lines = sum(torch.exp(-0.5 * ((x - c) / 6.0) ** 2)[None, :] for c in (300, 600, 1200, 1600) if c < length)
+        self.flux = torch.randn(n, length, generator=g) * 0.05 - (0.2 + 0.8 * self.labels[:, None]) * lines
+        self.error = 0.05 * torch.rand(n, length, generator=g)
+        if task == "cls":
+            self.labels = (self.labels * num_labels).long().clamp_(max=num_labels - 1)
+        elif num_labels > 1:
+            self.labels = self.labels[:, None].repeat(1, num_labels)
+        self.bs, self.shuffle, self.epoch, self.seed = batch_size, shuffle, 0, seed
+
+    def set_epoch(self, e):
+        self.epoch = e
+
+    def __iter__(self):
+        from vit_amd.ddp import shard_indices
+        import torch.distributed as dist
+
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        idx = shard_indices(self.flux.shape[0], rank, world, self.epoch, self.shuffle, self.seed)
+        for i in range(0, len(idx), self.bs):
+            j = idx[i:i + self.bs]
+            yield self.flux[j], self.error[j], self.labels[j]
+
+
+def main(args):
+    seed_everything(args.seed)
+    config = load_config(args.config)
+    if args.gpu is None:
+        args.gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    config.setdefault("train", {})
+    config["train"]["gpus"] = args.gpu
+    config["train"]["debug"] = args.debug
+    config["train"]["save"] = args.save
+    print(f"[Setup] Random seed: {args.seed}")
+    print("[Setup] Deterministic mode: ON")
+    module = ViTLModule(config=config)
+    if args.ckpt:
+        sd = torch.load(args.ckpt, map_location="cpu", weights_only=True)
+        sd = sd.get("state_dict", sd)
+        module.model.load_state_dict({k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()})
+    m = config["model"]
+    bs = config["train"].get("batch_size", 64)
+    mk = lambda n, seed, shuffle: SyntheticSpectra(n, m["image_size"], bs, m["task_type"], module.model.config.num_labels,
+                                                   seed, shuffle)
+    train, val = mk(args.synthetic, 1, not args.debug), mk(max(bs, args.synthetic // 8), 2, False)
+    trainer = Trainer(config["train"])
+    hist = trainer.fit(module, train, val)
+    test_logs = trainer.test(module, mk(max(bs, args.synthetic // 8), 3, False))
+    if trainer.rank == 0:
+        print("[test] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(test_logs.items())))
+        if args.save:
+            ckpt_dir = os.environ.get("CKPT_DIR", "./checkpoints")
+            os.makedirs(ckpt_dir, exist_ok=True)
+            path = os.path.join(ckpt_dir, f"{module.model.name}-last.pt")
+            torch.save({k: v.cpu() for k, v in module.model.state_dict().items()}, path)
+            print(f"[save] {path}")
+    return hist
+
+
+if __name__ == "__main__":
+    main(parse_args())
