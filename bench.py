@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--precision", default="bf16-mixed", choices=["bf16-mixed", "32"],
+                    help="bf16-mixed = the BASELINE.json metric; 32 = the fp32-class mode (x3 GEMMs), for the record only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
     args = ap.parse_args()
@@ -83,7 +85,7 @@ def main():
     config = {
         "model": dict(name="vit", task_type="reg", image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
                       num_attention_heads=heads, stride_size=P, proj_fn="SW"),
-        "train": dict(batch_size=B, ep=1, precision="bf16-mixed"),
+        "train": dict(batch_size=B, ep=1, precision=args.precision),
         "loss": {"name": "mae"},
         "opt": {"type": "AdamW", "lr": 1e-3},
         "data": {"param": "log_g"},
@@ -203,7 +205,7 @@ def main():
             "metric": "images/sec ViT-B/16 224^2 bf16 train step" if args.workload == "vit_b16_224" else f"images/sec {args.workload} bf16 train step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if args.precision == "bf16-mixed" else "f32 (split-bf16 x3 MFMA)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
                        "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
