@@ -45,8 +45,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
 /* Process-wide tuning / diagnostics knobs (never change results beyond rounding order):
  *   "gemm_core": 0 = generic 128x128 core only, 1 = automatic (default); on tile-aligned problems 2 / 3 / 4 force the
  *                LDS-DMA core's 256x256xBK64 (2 stages) / 256x128xBK64 (3 stages) / 256x256xBK32 (4 stages) geometry,
- *                5 the staggered 256x256xBK32 variant (wave halves alternate LOAD and MFMA roles), 6 the 4-wave
- *                256x128xBK32 (3 stages) geometry with two workgroups per CU.
+ *                5 the 256x256xBK64 ping-pong variant (wave halves one barrier out of phase: LOAD segment beside MFMA
+ *                segment, ring of 8 half-tiles, 4 in flight), 6 the 4-wave 256x128xBK32 (3 stages) geometry with two
+ *                workgroups per CU.
  *   "gemm_debug": timing diagnostics for the LDS-DMA core (1 = skip operand DMA after the prologue, 2 = skip MFMAs);
  *                results are meaningless while it is non-zero.
  *                Returns VIT_ERR_ARG for an unknown name. */

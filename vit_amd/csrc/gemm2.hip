@@ -306,23 +306,41 @@ static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hi
   return launch_one<BM, BN, BK, NSTAGE, NW, 1, 1, 0>(a, grid, st);
 }
 
-// ------------------------------------------------------------------------------------------------ staggered variant
-// 256x256 tile, BK = 32, 4-stage ring, 3 K-tiles in flight.  The two wave halves (waves 0-3 / 4-7: partners on the
-// same SIMDs) run the K loop half a K-tile out of phase: in every phase one half is in its MFMA role (32 MFMAs per
-// wave on fragments it read in the previous phase) while the other is in its LOAD role (issue its share of the DMA for
-// K-tile t+3, read the fragments of K-tile t from the LDS).  One barrier per phase; all DMA waits sit at the end of odd
-// phases ("my parts of K-tile (ph+1)/2 have landed"), so a tile is complete one barrier before its first reader.
+// ------------------------------------------------------------------------------------------------ ping-pong variant
+// 256x256x64 tiles, 8 waves as 2 (M) x 4 (N), the "8-phase" structure: the two wave groups (waves 0-3 / 4-7: partners on
+// the same four SIMDs) run ONE BARRIER out of phase, so that in every barrier interval one group is in a LOAD segment
+// (its LDS fragment reads + its share of one half-tile's LDS-DMA) while the other is in an MFMA segment (16 MFMAs = one
+// 64x32 quadrant of its 128x64 output over the whole K-tile, at s_setprio 1).  The matrix pipe of every SIMD always has a
+// wave feeding it and fragment-read latency is never in front of an MFMA.
+//
+// LDS ring: 2 K-tiles x 4 HALF-tiles (A0, B0, B1, A1) of 16 KiB.  Half h of A holds rows wr*128 + h*64 .. +64 of both
+// wave rows, half h of B the columns wc*64 + h*32 .. +32 of all four wave columns, so one phase needs one (A-half, B-half)
+// pair and a half-tile is dead -- restageable -- long before the K-tile is finished.  Per K-tile `it`:
+//   phase  MFMA quadrant   LDS reads (b128)        LDS-DMA issued (stream index p + 5)
+//   P1     (A0, B0)        B0(it) 4, A0(it) 8      B1(it+1)
+//   P2     (A0, B1)        B1(it) 4                A1(it+1)
+//   P3     (A1, B1)        A1(it) 8                A0(it+2)
+//   P4     (A1, B0)        -                       B0(it+2)
+// Half-tiles stream in the order they are first read (A0, B0, B1, A1 per K-tile); stream index h is issued in phase h - 5
+// (the first phase that is >= 2 phases after the last read of the slot it overwrites) and every phase ends its LOAD
+// segment with s_waitcnt vmcnt(8): everything up to stream index p + 1 -- what phase p + 1 reads -- has landed, four
+// half-tiles (64 KiB per CU) stay in flight across the barriers.  A wait in phase w orders reads in phase >= w + 1 for
+// both groups (the staggered group reads one barrier later still).  The loop is flat over (output tile, K-tile), so the
+// stream runs through tile boundaries; at a boundary the groups re-align (one extra barrier each, on opposite sides of
+// the epilogue) so that all eight waves run their epilogues concurrently, and the first four phases after it count the
+// epilogue's >= 32 stores per wave into the vmcnt budget instead of draining them.
 template <int A_T, int B_T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
-  constexpr int BM = 256, BN = 256, BK = 32, NST = 4, S = 3, NW = 8;
-  constexpr int WM = 8, WN = 4;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int GA = A_BYTES / 8192, GB = B_BYTES / 8192, G = GA + GB;  // 4 DMA instructions per wave per K-tile
-  constexpr int RING = NST * STAGE, SCR = (160 * 1024 - RING) / NW, CW = SCR / 64;
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int HALF = 128 * BK * 2;     // one half-tile image: 16 KiB
+  constexpr int RING = 8 * HALF;         // 2 K-tiles x 4 half-tiles
+  constexpr int SCR = 4096, CW = 64;     // epilogue scratch per wave
+  constexpr int XA0 = 0, XB0 = 1, XB1 = 2, XA1 = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3, grp = wave >> 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, grp = wr;
   const int l15 = lane & 15, lg = lane >> 4;
 
   const int split = blockIdx.y;
@@ -332,13 +350,30 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   const int ntile = p.tiles_m * p.tiles_n;
   const int bx = blockIdx.x, nblk = p.nblk;
   const int my_tiles = (ntile - bx + nblk - 1) / nblk;
-  const int T = my_tiles * nk;
+  const int T = my_tiles * nk;  // K-tiles this workgroup walks
 
-  int offA[GA], offB[GB];
+  // per-thread DMA source offsets (elements) of the two 8-KiB rounds of a half-tile, relative to (tile origin, k0, half 0)
+  int offA[2], offB[2];
 #pragma unroll
-  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK, 8>(i, wave, lane, (int)p.lda);
-#pragma unroll
-  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK, 8>(i, wave, lane, (int)p.ldb);
+  for (int i = 0; i < 2; ++i) {
+    if (A_T == 0) {
+      const int rimg = i * 64 + wave * 8 + (lane >> 3);
+      offA[i] = (i * 128 + wave * 8 + (lane >> 3)) * (int)p.lda + (((lane & 7) ^ ((rimg >> 1) & 7)) << 3);
+    } else {
+      const int k = i * 32 + wave * 4 + (lane >> 4);
+      const int c16 = (lane & 15) ^ (tr_swz2(k) >> 1);
+      offA[i] = k * (int)p.lda + (c16 >> 3) * 128 + ((c16 & 7) << 3);
+    }
+    if (B_T == 0) {
+      const int rimg = i * 64 + wave * 8 + (lane >> 3);
+      offB[i] = ((rimg >> 5) * 64 + (rimg & 31)) * (int)p.ldb + (((lane & 7) ^ ((rimg >> 1) & 7)) << 3);
+    } else {
+      const int k = i * 32 + wave * 4 + (lane >> 4);
+      const int c16 = (lane & 15) ^ (tr_swz2(k) >> 1);
+      offB[i] = k * (int)p.ldb + (c16 >> 2) * 64 + ((c16 & 3) << 3);
+    }
+  }
+  const long halfA = (A_T == 0) ? 64 * p.lda : 64, halfB = (B_T == 0) ? 32 * p.ldb : 32;  // elements to half 1
 
   auto tile_coords = [&](int j, int& tm, int& tn) {
     const int round0 = j * nblk;
@@ -349,98 +384,146 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     tm = t / p.tiles_n;
     tn = t - tm * p.tiles_n;
   };
-  auto issue = [&](int it) {
-    const int j = it / nk, kt = it - j * nk;
-    int tm, tn;
-    tile_coords(j, tm, tn);
+  // global bases (A, B) of K-tile kt of output tile (tm, tn)
+  auto base_of = [&](int tm, int tn, int kt, const char*& ab, const char*& bb) {
     const int k0 = k_begin + kt * BK;
-    const char* ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
-    const char* bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
-    char* st = smem + (it % NST) * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * 8192), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < GB; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * 8192), 16, 0, 0);
+    ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
+    bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
+  };
+  // walking cursor over this workgroup's flat (output tile, K-tile) sequence: no division in the loop
+  int cj = 0, ckt = 0, ctm, ctn;
+  tile_coords(0, ctm, ctn);
+  auto cursor_next = [&](const char*& ab, const char*& bb) {  // bases of the cursor's K-tile, then advance
+    base_of(ctm, ctn, ckt, ab, bb);
+    if (++ckt == nk) {
+      ckt = 0;
+      if (++cj < my_tiles) tile_coords(cj, ctm, ctn);
+    }
+  };
+  // one half-tile = 2 LDS-DMA instructions per thread; destination: slot + round*8 KiB + wave*1 KiB (+ lane*16)
+  auto issue_half = [&](const char* base, long half_off, const int (&off)[2], int it, int x) {
+    char* dst = smem + (((it & 1) << 2) + x) * HALF + wave * 1024;
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
   };
 
+  // ---- fragment reads
   const int tq = l15 >> 2, tp = l15 & 3;
   const int tr_f = (tq | ((lg & 1) << 2)) << 2;
-  const int kc_off = l15 * 64 + ((lg ^ ((-(l15 >> 2)) & 3)) << 4);
-  auto read_frag = [&](const char* img, int trans, int rb_bytes, int base16) -> bf16x8 {
+  int kc_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) kc_off[s] = l15 * 128 + (((s * 4 + lg) ^ (l15 >> 1)) << 4);
+  auto read_frag = [&](const char* img, int trans, int base16, int s) -> bf16x8 {
     if (!trans) {
-      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off);
+      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off[s]);
     } else {
-      const char* pa = img + (lg * 8 + tq) * rb_bytes + ((((base16 >> 2) + tp) ^ tr_f) << 3);
+      const char* pa = img + (s * 32 + lg * 8 + tq) * 256 + ((((base16 >> 2) + tp) ^ tr_f) << 3);
       bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
-      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * rb_bytes));
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * 256));
       return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
   };
 
-  f32x4 acc[WM][WN];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < WM; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[WM], bf[WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < WN; ++j) bf[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], b0[2][2], b1[2][2];
 
-#pragma unroll
-  for (int pre = 0; pre < S; ++pre)
-    if (pre < T) issue(pre);
-  if (S - 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * G) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define PP_READ_A(IMG)                                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
+      af[i_][s_] = read_frag(IMG, A_T, wr * 64 + i_ * 16, s_);
+#define PP_READ_B(BF, IMG)                                                                       \
+  _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
+      BF[j_][s_] = read_frag(IMG, B_T, wc * 32 + j_ * 16, s_);
+// end of a LOAD segment -> MFMA segment on quadrant (HA, HB) -> closing barrier
+#define PP_MFMA(HA, HB, BF)                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+          acc[HA * 4 + i_][HB * 2 + j_] =                                                        \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j_][s_], af[i_][s_], acc[HA * 4 + i_][HB * 2 + j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
   __builtin_amdgcn_s_barrier();
+// stage one half-tile of K-tile IT (if it exists) and leave four half-tiles in flight; `relaxed`: the epilogue's stores
+// were issued after the three older half-tiles still in flight -- count them in instead of draining them
+#define PP_STAGE(IT, BASE, HOFF, OFF, X)                                                         \
+  if ((IT) < T) {                                                                                \
+    issue_half(BASE, HOFF, OFF, IT, X);                                                          \
+    if (relaxed) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
+  } else {                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+  }
+
+  // ---- prologue: stream indices 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
+  const char *a1 = nullptr, *bb1 = nullptr, *a2 = nullptr, *bb2 = nullptr;  // bases of K-tiles it+1, it+2
+  {
+    const char *a0, *bb0;
+    cursor_next(a0, bb0);
+    issue_half(a0, 0, offA, 0, XA0);
+    issue_half(bb0, 0, offB, 0, XB0);
+    issue_half(bb0, halfB, offB, 0, XB1);
+    issue_half(a0, halfA, offA, 0, XA1);
+    if (1 < T) {
+      cursor_next(a1, bb1);
+      issue_half(a1, 0, offA, 1, XA0);
+      issue_half(bb1, 0, offB, 1, XB0);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    if (2 < T) cursor_next(a2, bb2);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
 
   char* scr = smem + RING + wave * SCR;
-  int ktM = 0, jtM = 0;
-  for (int ph = 0; ph <= 2 * T; ++ph) {
-    if ((ph & 1) == grp) {
-      // ---- LOAD role: K-tile t
-      const int t = (ph - grp) >> 1;
-      if (t < T) {
-        if (t + S < T) issue(t + S);
-        const char* As = smem + (t % NST) * STAGE;
-        const char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = read_frag(As, A_T, BM * 2, (wm * WM + i) * 16);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bf[j] = read_frag(Bs, B_T, BN * 2, (wn * WN + j) * 16);
-      }
-    } else {
-      // ---- MFMA role: K-tile t (fragments were read in the previous phase)
-      const int t = (ph - 1 - grp) >> 1;
-      if (t >= 0 && t < T) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (++ktM == nk) {
-          ktM = 0;
-          int tm, tn;
-          tile_coords(jtM, tm, tn);
-          ++jtM;
-          tile_epilogue<WM, WN, CW, EPI>(acc, scr, p, tm * BM + wm * WM * 16, tn * BN + wn * WN * 16, split, lane);
-        }
-      }
+  int kt = 0, jt = 0;
+  bool relaxed = false;
+  for (int it = 0; it < T; ++it) {
+    const char* ring = smem + ((it & 1) << 2) * HALF;
+    // P1
+    PP_READ_B(b0, ring + XB0 * HALF)
+    PP_READ_A(ring + XA0 * HALF)
+    PP_STAGE(it + 1, bb1, halfB, offB, XB1)
+    PP_MFMA(0, 0, b0)
+    // P2
+    PP_READ_B(b1, ring + XB1 * HALF)
+    PP_STAGE(it + 1, a1, halfA, offA, XA1)
+    PP_MFMA(0, 1, b1)
+    // P3
+    PP_READ_A(ring + XA1 * HALF)
+    PP_STAGE(it + 2, a2, 0, offA, XA0)
+    PP_MFMA(1, 1, b1)
+    // P4
+    PP_STAGE(it + 2, bb2, 0, offB, XB0)
+    PP_MFMA(1, 0, b0)
+    relaxed = false;
+    a1 = a2; bb1 = bb2;
+    if (it + 3 < T) cursor_next(a2, bb2);
+    if (++kt == nk) {
+      kt = 0;
+      int tm, tn;
+      tile_coords(jt, tm, tn);
+      ++jt;
+      if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
+      tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
+      if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
+      relaxed = true;
     }
-    if (ph & 1) {
-      const int tw = (ph + 1) >> 1;  // my parts of this K-tile must have landed before the barrier
-      if (tw < T) {
-        if (tw + S - 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 1) * G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    __builtin_amdgcn_s_barrier();
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier of the other group
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+#undef PP_STAGE
 }
 
 template <int AT, int BT, int EPI>
@@ -475,7 +558,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     g_gemm2_mode = e ? atoi(e) : 1;
   }
   // 0 = off; 1 = automatic; 2 = 256x256 BK64 x2 stages; 3 = 256x128 BK64 x3 stages; 4 = 256x256 BK32 x4 stages;
-  // 5 = 256x256 BK32 x4 stages with the two wave halves staggered (LOAD role || MFMA role);
+  // 5 = 256x256 BK64 ping-pong: wave halves one barrier out of phase (LOAD segment || MFMA segment), 8 half-tile ring;
   // 6 = 256x128 BK32 x3 stages, 4 waves, TWO workgroups per CU
   const int mode = g_gemm2_mode;
   if (mode == 0) return 0;
@@ -489,12 +572,12 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     if (d->a_trans || !d->b_trans) return 0;
     epi = 2;
   }
-  // automatic choice, from tools/gemm_bench.py on the ViT-B shapes (MI355X): the 256x256xBK64 LDS-DMA geometry wins for
-  // Y = X W^T and dW = dY^T X with N >= 2304 (QKV and FC1 forward +35 %, FC2's dW +10 %); the register-staged 128x128
-  // core (two independent workgroups per CU) wins or ties everywhere else, notably for dX = dY W.
+  // automatic choice, from tools/gemm_bench.py on the ViT-B shapes (MI355X): the ping-pong kernel wins on every one of
+  // the twelve GEMMs of a layer (2.98 ms per layer against 3.41 ms for the best of the other cores); problems whose N
+  // is not a multiple of 256 stay on the register-staged 128x128 core.
   int cfg = mode;
   if (mode == 1) {
-    if (d->a_trans == d->b_trans && d->N >= 2304 && d->N % 256 == 0) cfg = 2;
+    if (d->N % 256 == 0) cfg = 5;
     else return 0;
   }
   if (d->N % 256 && cfg != 6) cfg = 3;
