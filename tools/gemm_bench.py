@@ -39,6 +39,8 @@ def main():
         "fwd out   [M,768]x[768,768]^T +b,drop,res": (lambda: vf.gemm(x768, Wo, M=M, N=D, K=D, out=o768f, bias=bias768, dropout=drop, residual=res), 2 * M * D * D),
         "fwd fc1   [M,768]x[3072,768]^T +b,gelu": (lambda: vf.gemm(x768, W1, M=M, N=F, K=D, out=o3072, bias=bias3072, act=ACT_GELU, aux_out=aux), 2 * M * F * D),
         "fwd fc2   [M,3072]x[768,3072]^T +b,drop,res": (lambda: vf.gemm(x3072, W2, M=M, N=D, K=F, out=o768f, bias=bias768, dropout=drop, residual=res), 2 * M * F * D),
+        "fwd out'  [M,768]x[768,768]^T +b,drop -> bf16": (lambda: vf.gemm(x768, Wo, M=M, N=D, K=D, out=o768, bias=bias768, dropout=drop), 2 * M * D * D),
+        "fwd fc2'  [M,3072]x[768,3072]^T +b,drop -> bf16": (lambda: vf.gemm(x3072, W2, M=M, N=D, K=F, out=o768, bias=bias768, dropout=drop), 2 * M * F * D),
         "dX  fc2   [M,768]x[768,3072] *dgelu": (lambda: vf.gemm(x768, W2, M=M, N=F, K=D, b_trans=True, out=o3072, act=ACT_DGELU, aux_in=aux), 2 * M * F * D),
         "dX  fc1   [M,3072]x[3072,768]": (lambda: vf.gemm(x3072, W1, M=M, N=D, K=F, b_trans=True, out=o768), 2 * M * F * D),
         "dX  out   [M,768]x[768,768]": (lambda: vf.gemm(x768, Wo, M=M, N=D, K=D, b_trans=True, out=o768), 2 * M * D * D),

@@ -306,6 +306,84 @@ static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hi
   return launch_one<BM, BN, BK, NSTAGE, NW, 1, 1, 0>(a, grid, st);
 }
 
+// Specialised epilogues of the ping-pong kernel (FAST): what the five hot GEMM kinds of a ViT layer need, with every
+// decision at compile time so that no load sits behind a runtime branch (hipcc waits vmcnt(0) after each such load,
+// and, beside LDS-DMA in flight, after ANY load: 32 serialised HBM round trips per tile in the generic epilogue):
+//   3 = (+bias) (+dropout) -> bf16      Y = X W^T of the QKV / attention-output / FC2 projections
+//   4 = +bias, erf-GELU (pre-activation saved to aux_out when given) -> bf16        FC1
+//   5 = * gelu'(aux_in) -> bf16         dX of FC2; the wave's 32 aux rows are fetched in ONE batch up front
+//   6 = plain -> bf16                   dX = dY W
+//   7 = plain -> f32 (C or split-K slab)  dW = dY^T X
+// Same per-wave LDS transpose as tile_epilogue: a lane ends up owning 4 consecutive columns of rows rr*4 + lane/16.
+template <int FAST>
+__device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
+                                            int lane) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int n = n0 + l15 * 4;           // this lane's 4 output columns (row-major side)
+  const int rsub = lane >> 4;           // its row inside each group of 4 rows
+  const unsigned half_cols = (unsigned)(p.N >> 1);
+  f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if ((FAST == 3 || FAST == 4) && p.bias) bv = *(const f32x4*)(p.bias + n);
+  u32x2 au[4][4];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile: 64 aux VGPRs spill)
+  float* cf = (FAST == 7) ? (p.splits > 1 ? p.slab + (long)split * p.M * p.N : (float*)p.C) : nullptr;
+  const long ldc = (FAST == 7 && p.splits > 1) ? (long)p.N : p.ldc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (FAST == 5 && (i & 3) == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          au[ii][rr] = *(const u32x2*)(p.aux_in + (long)(m0 + (i + ii) * 16 + rr * 4 + rsub) * p.ldaux + n);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c16 = j * 4 + lg;
+      *(f32x4*)(scr + l15 * 256 + ((c16 ^ l15) << 4)) = acc[i][j];
+      acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 v[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = rr * 4 + rsub;
+      v[rr] = *(const f32x4*)(scr + row * 256 + ((l15 ^ row) << 4));
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const long m = m0 + i * 16 + rr * 4 + rsub;
+      f32x4 o = v[rr];
+      if (FAST == 7) {
+        *(f32x4*)(cf + m * ldc + n) = o;
+        continue;
+      }
+      if (FAST == 3 || FAST == 4) o += bv;
+      if (FAST == 4) {
+        if (p.aux_out) {
+          u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+          *(u32x2*)(p.aux_out + m * p.ldaux + n) = pk;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+      }
+      if (FAST == 5) {
+        const u32x2 u = au[i & 3][rr];
+        o[0] *= dgelu_erf(__builtin_bit_cast(float, u[0] << 16));
+        o[1] *= dgelu_erf(__builtin_bit_cast(float, u[0] & 0xFFFF0000u));
+        o[2] *= dgelu_erf(__builtin_bit_cast(float, u[1] << 16));
+        o[3] *= dgelu_erf(__builtin_bit_cast(float, u[1] & 0xFFFF0000u));
+      }
+      if (FAST == 3 && p.drop.thr) {
+        float k0, k1, k2, k3;
+        drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n, k0, k1);
+        drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n + 2, k2, k3);
+        o[0] *= k0; o[1] *= k1; o[2] *= k2; o[3] *= k3;
+      }
+      u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+      *(u32x2*)(p.C + (m * p.ldc + n) * 2) = pk;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ ping-pong variant
 // 256x256x64 tiles, 8 waves as 2 (M) x 4 (N), the "8-phase" structure: the two wave groups (waves 0-3 / 4-7: partners on
 // the same four SIMDs) run ONE BARRIER out of phase, so that in every barrier interval one group is in a LOAD segment
@@ -514,7 +592,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
       tile_coords(jt, tm, tn);
       ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
-      tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
+      if constexpr (EPI >= 3) pp_epilogue<EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
+      else tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
       relaxed = true;
     }
@@ -542,6 +621,11 @@ static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
 static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
   if (epi == 1) return launch_stag<0, 0, 1>(a, grid, st);
   if (epi == 2) return launch_stag<0, 1, 2>(a, grid, st);
+  if (epi == 3) return launch_stag<0, 0, 3>(a, grid, st);
+  if (epi == 4) return launch_stag<0, 0, 4>(a, grid, st);
+  if (epi == 5) return launch_stag<0, 1, 5>(a, grid, st);
+  if (epi == 6) return launch_stag<0, 1, 6>(a, grid, st);
+  if (epi == 7) return launch_stag<1, 1, 7>(a, grid, st);
   if (!at && !bt) return launch_stag<0, 0, 0>(a, grid, st);
   if (!at && bt) return launch_stag<0, 1, 0>(a, grid, st);
   if (at && !bt) return launch_stag<1, 0, 0>(a, grid, st);
@@ -630,17 +714,27 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.debug = g_gemm2_debug;
 
   dim3 grid(a.nblk, splits);
+  int epi5 = epi;  // ping-pong kernel: the specialised epilogue when the descriptor is one of the five hot kinds
+  if (cfg == 5) {
+    const bool plain = !a.residual && a.rpb == 0 && d->alpha == 1.0f;
+    if (epi == 1 && plain && a.bias && d->c_dtype == VIT_BF16 && !a.drop.thr && splits == 1) epi5 = 4;
+    else if (epi == 2 && plain && !a.bias && d->c_dtype == VIT_BF16 && !a.drop.thr && splits == 1) epi5 = 5;
+    else if (epi == 0 && plain && d->c_dtype == VIT_BF16 && !d->a_trans && !d->b_trans && splits == 1) epi5 = 3;
+    else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_BF16 && !d->a_trans && d->b_trans &&
+             splits == 1) epi5 = 6;
+    else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_F32 && d->a_trans && d->b_trans) epi5 = 7;
+  }
   {
     static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
-    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d>", at, bt, epi);
+    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d>", at, bt, epi5);
     else snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", geo[cfg][0], geo[cfg][1],
                   geo[cfg][2], geo[cfg][3], geo[cfg][4], at, bt, epi);
   }
   int r;
   if (cfg == 2) r = launch_cfg<256, 256, 64, 2, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   else if (cfg == 3) r = launch_cfg<256, 128, 64, 3, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi, grid, st);
+  else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
   else if (cfg == 6) r = launch_cfg<256, 128, 32, 3, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
   else r = launch_cfg<256, 256, 32, 4, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   if (r == VIT_OK && splits > 1)
