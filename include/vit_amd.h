@@ -110,6 +110,13 @@ int vit_linear_bwd_dw(vit_handle h, const void* dy, const void* x, float* dW, in
  */
 int vit_layernorm_fwd(vit_handle h, const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                       float* mean, float* rstd, int rows, int D, float eps, vit_stream stream);
+/* The same LayerNorm over x + delta, where delta (delta_dtype [rows, D]) is the output of the Linear underneath a
+ * "dropout(Linear(.)) + residual" (HF ViTLayer: attention_output + hidden_states; ViTOutput: hidden_states + input_tensor),
+ * and xsum (f32 [rows, D]) receives the sum: the residual add rides on the pass that reads the stream anyway, so the
+ * projection GEMMs write bf16 and never load. */
+int vit_layernorm_fwd_residual(vit_handle h, const float* x, const void* delta, int delta_dtype, float* xsum,
+                               const float* gamma, const float* beta, void* y, int y_dtype, float* mean, float* rstd,
+                               int rows, int D, float eps, vit_stream stream);
 /* dx[rows,D] (f32) = LN'(dy) (+ dres if not NULL: the residual branch's gradient); dgamma/dbeta (f32 [D]) are
  * reduced deterministically through the workspace; accumulate!=0 adds into them. dy: dy_dtype [rows, D]. */
 int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,

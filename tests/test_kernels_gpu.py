@@ -459,6 +459,25 @@ def test_layernorm_bwd_fused(dev, rows, D):
         assert rel(dg1, dg0) < 1e-6 and rel(db1, db0) < 1e-6 and rel(dbias1, dbias0) < 1e-5
 
 
+@pytest.mark.parametrize("rows,D", [(37, 32), (1000, 192), (3940, 768), (129, 1024)])
+@pytest.mark.parametrize("ddt", [torch.bfloat16, torch.float32])
+def test_layernorm_fwd_residual(dev, rows, D, ddt):
+    """LayerNorm over x + delta with the sum written back (the residual add of ViTLayer / ViTOutput): the sum is exact,
+    statistics and output equal the plain kernel's on the summed rows bit for bit."""
+    import vit_amd.functional as vf
+
+    x = randn((rows, D), dev, 90) * 2 + 0.3
+    delta = (randn((rows, D), dev, 91)).to(ddt)
+    g, b = randn((D,), dev, 92) * 0.1 + 1, randn((D,), dev, 93) * 0.1
+    xs = torch.empty_like(x)
+    for odt in (torch.bfloat16, torch.float32):
+        y, mean, rstd = vf.layernorm_fwd_residual(x, delta, xs, g, b, 1e-12, out_dtype=odt)
+        ref_sum = x + delta.float()
+        assert torch.equal(xs, ref_sum)
+        y0, mean0, rstd0 = vf.layernorm_fwd(ref_sum, g, b, 1e-12, out_dtype=odt)
+        assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+
+
 # ------------------------------------------------------------------ fp32-class kernels (precision='32')
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 192, 192), (104, 40, 72), (516, 96, 32), (1024, 768, 768)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])

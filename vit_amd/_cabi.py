@@ -59,6 +59,7 @@ _PROTOS = {
     "vit_linear_bwd_dx": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "vit_linear_bwd_dw": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vit_layernorm_fwd": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
+    "vit_layernorm_fwd_residual": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     "vit_layernorm_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "vit_layernorm_bwd_fused": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _F, _U64, _U64, _P],
     "vit_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],

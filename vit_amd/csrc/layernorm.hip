@@ -11,11 +11,14 @@ namespace vit {
 void* ctx_workspace(vit_handle h, size_t* bytes);
 
 // NV = float4 chunks per lane held in registers; supports D <= 256*NV
-template <int NV, int OUT_BF16>
+// RES: 0 = plain; 1 / 2 = the row normalised is x + delta (delta bf16 / f32: the projection underneath a
+// "dropout(Linear(.)) + residual"), and the sum is also written to xsum -- the new residual stream.
+template <int NV, int OUT_BF16, int RES>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int D, float eps) {
+                                                     int D, float eps, const void* __restrict__ delta,
+                                                     float* __restrict__ xsum) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -29,6 +32,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       v[i] = (c < nvec) ? *(const f32x4*)(xr + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (RES && c < nvec) {
+        if (RES == 1) {
+          const bf16x4 t = *(const bf16x4*)((const short*)delta + (long)row * D + 4 * c);
+          v[i] += (f32x4){bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        } else {
+          v[i] += *(const f32x4*)((const float*)delta + (long)row * D + 4 * c);
+        }
+        *(f32x4*)(xsum + (long)row * D + 4 * c) = v[i];
+      }
       s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mu = wave_sum(s) * invD;
@@ -167,12 +179,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-template <int OUT_BF16>
+template <int OUT_BF16, int RES>
 static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
-                           int D, float eps, hipStream_t st) {
+                           int D, float eps, hipStream_t st, const void* delta = nullptr, float* xsum = nullptr) {
   const int blocks = std::min(cdiv(rows, 4), 2048);
   const int nv = cdiv(D, 256);
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, OUT_BF16>), dim3(blocks), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, D, eps)
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, OUT_BF16, RES>), dim3(blocks), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, D, eps, delta, xsum)
   if (nv <= 1) LAUNCH(1);
   else if (nv <= 2) LAUNCH(2);
   else if (nv <= 3) LAUNCH(3);
@@ -240,8 +252,25 @@ int vit_layernorm_fwd(vit_handle h, const float* x, const float* gamma, const fl
   VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_fwd: rows=%d D=%d (D must be a multiple of 4)", rows, D);
   VIT_CHECK(y_dtype == VIT_BF16 || y_dtype == VIT_F32, VIT_ERR_ARG, "vit_layernorm_fwd: bad y_dtype");
   hipStream_t st = (hipStream_t)stream;
-  return y_dtype == VIT_BF16 ? ln_fwd_dispatch<1>(x, gamma, beta, y, mean, rstd, rows, D, eps, st)
-                             : ln_fwd_dispatch<0>(x, gamma, beta, y, mean, rstd, rows, D, eps, st);
+  return y_dtype == VIT_BF16 ? ln_fwd_dispatch<1, 0>(x, gamma, beta, y, mean, rstd, rows, D, eps, st)
+                             : ln_fwd_dispatch<0, 0>(x, gamma, beta, y, mean, rstd, rows, D, eps, st);
+}
+
+int vit_layernorm_fwd_residual(vit_handle h, const float* x, const void* delta, int delta_dtype, float* xsum,
+                               const float* gamma, const float* beta, void* y, int y_dtype, float* mean, float* rstd,
+                               int rows, int D, float eps, vit_stream stream) {
+  using namespace vit;
+  (void)h;
+  VIT_CHECK(x && delta && xsum && gamma && beta && y, VIT_ERR_ARG, "vit_layernorm_fwd_residual: null pointer");
+  VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_fwd_residual: rows=%d D=%d (D must be a multiple of 4)", rows, D);
+  VIT_CHECK((y_dtype == VIT_BF16 || y_dtype == VIT_F32) && (delta_dtype == VIT_BF16 || delta_dtype == VIT_F32), VIT_ERR_ARG,
+            "vit_layernorm_fwd_residual: bad dtype");
+  hipStream_t st = (hipStream_t)stream;
+  if (delta_dtype == VIT_BF16)
+    return y_dtype == VIT_BF16 ? ln_fwd_dispatch<1, 1>(x, gamma, beta, y, mean, rstd, rows, D, eps, st, delta, xsum)
+                               : ln_fwd_dispatch<0, 1>(x, gamma, beta, y, mean, rstd, rows, D, eps, st, delta, xsum);
+  return y_dtype == VIT_BF16 ? ln_fwd_dispatch<1, 2>(x, gamma, beta, y, mean, rstd, rows, D, eps, st, delta, xsum)
+                             : ln_fwd_dispatch<0, 2>(x, gamma, beta, y, mean, rstd, rows, D, eps, st, delta, xsum);
 }
 
 int vit_layernorm_bwd(vit_handle h, const void* dy, int dy_dtype, const float* x, const float* gamma,

@@ -266,6 +266,7 @@ class ViTEngine:
             mean1=[E((M,), f32) for _ in range(nl)], rstd1=[E((M,), f32) for _ in range(nl)],
             mean2=[E((M,), f32) for _ in range(nl)], rstd2=[E((M,), f32) for _ in range(nl)],
             last=E((B, T, D), f32), meanF=E((M,), f32), rstdF=E((M,), f32),
+            y=E((M, D), b16),  # dropout(Linear(.)) of the attention-output / FC2 projection, until the next LayerNorm adds it
         )
         self.tmp = {}
         if train:
@@ -314,25 +315,36 @@ class ViTEngine:
         vf.embed_finish(x0, self.p(e + "cls_token").view(D), pos, dropout=(ph, seed, 0))
 
         atts = [] if output_attentions else None
+        # The two "dropout(Linear(.)) + residual" sums of a layer (HF ViTLayer / ViTOutput) are formed by the LayerNorm
+        # that consumes them: the projection GEMM writes y = dropout(acc + bias) in the activation dtype, the LayerNorm
+        # pass reads the f32 stream and y, writes the new stream and its normalised operand (vit_layernorm_fwd_residual).
+        y = a["y"]
         for i in range(L):
             j = i if need_grad else 0
             pre = f"vit.encoder.layer.{i}."
             xin = a["x"][i].view(M, D)
-            self._ln(xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
+            if i == 0:
+                self._ln(xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
+            else:
+                self._ln_res(a["x1"][jprev], y, xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
             vf.gemm(a["h1"][j], self._qkv16(i), M=M, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
             vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
                              lse=a["lse"][j])
             if output_attentions:
                 atts.append(vf.attention_probs(a["qkv"][j], B, H, T, dh, scale))
-            vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, out=a["x1"][j],
-                    bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)),
-                    residual=xin)
-            self._ln(a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
+            vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, out=y,
+                    bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)))
+            self._ln_res(xin, y, a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
             vf.gemm(a["h2"][j], self.w16(pre + "intermediate.dense.weight"), M=M, N=Fd, K=D, out=a["g"][j],
                     bias=self.p(pre + "intermediate.dense.bias"), act=ACT_GELU, aux_out=a["u"][j] if need_grad else None)
-            vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=M, N=D, K=Fd, out=a["x"][i + 1].view(M, D),
-                    bias=self.p(pre + "output.dense.bias"), dropout=(ph, seed, self._site(i, 2)), residual=a["x1"][j])
-        self._ln(a["x"][L].view(M, D), "vit.layernorm", a["last"].view(M, D), a["meanF"], a["rstdF"])
+            vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=M, N=D, K=Fd, out=y,
+                    bias=self.p(pre + "output.dense.bias"), dropout=(ph, seed, self._site(i, 2)))
+            jprev = j
+        if L > 0:
+            self._ln_res(a["x1"][jprev], y, a["x"][L].view(M, D), "vit.layernorm", a["last"].view(M, D), a["meanF"],
+                         a["rstdF"])
+        else:
+            self._ln(a["x"][L].view(M, D), "vit.layernorm", a["last"].view(M, D), a["meanF"], a["rstdF"])
         hn = self.layout.head
         if labels is not None:
             labels = labels.to(self.flat.device)
@@ -348,6 +360,10 @@ class ViTEngine:
     def _ln(self, x, name, out, mean, rstd):
         vf.layernorm_fwd(x, self.p(name + ".weight"), self.p(name + ".bias"), self.cfg.layer_norm_eps, out=out,
                          mean=mean, rstd=rstd)
+
+    def _ln_res(self, x, delta, xsum, name, out, mean, rstd):
+        vf.layernorm_fwd_residual(x, delta, xsum, self.p(name + ".weight"), self.p(name + ".bias"),
+                                  self.cfg.layer_norm_eps, out=out, mean=mean, rstd=rstd)
 
     # ------------------------------------------------------------------ backward
     def backward(self, dloss: torch.Tensor):

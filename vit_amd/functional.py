@@ -115,6 +115,25 @@ def layernorm_fwd(x, gamma, beta, eps: float, out_dtype=torch.bfloat16, out=None
     return y, mean, rstd
 
 
+def layernorm_fwd_residual(x, delta, xsum, gamma, beta, eps: float, out_dtype=torch.bfloat16, out=None, mean=None,
+                           rstd=None):
+    """xsum = x + delta (f32 stream + bf16/f32 projection output); y = LayerNorm(xsum)."""
+    _chk(x, torch.float32, "layernorm_fwd_residual x")
+    _chk(xsum, torch.float32, "layernorm_fwd_residual xsum")
+    if delta.dtype not in _DT or not delta.is_contiguous() or delta.numel() != x.numel() or xsum.numel() != x.numel():
+        raise _cabi.VitError("layernorm_fwd_residual: delta must be a contiguous bf16/f32 tensor of x's shape")
+    h = _h(x)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = mean if mean is not None else torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = rstd if rstd is not None else torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(h.lib.vit_layernorm_fwd_residual(h.h, x.data_ptr(), delta.data_ptr(), _DT[delta.dtype], xsum.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _DT[y.dtype], _ptr(mean),
+                                           _ptr(rstd), rows, D, eps, _stream(x)), "vit_layernorm_fwd_residual")
+    return y, mean, rstd
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres=None, dx=None, dgamma=None, dbeta=None):
     _chk(x, torch.float32, "layernorm_bwd x")
     h = _h(x)
