@@ -98,14 +98,14 @@ __device__ __forceinline__ void drop_pair(const DropCfg& d, unsigned long long r
 // one v_rcp + one v_exp + 6 FMAs instead of libm's branchy erff (the GELU epilogue of the FC1 GEMM was VALU-bound).
 // cdf(x) = Phi(x) and pdf-exponential e^{-x^2/2} share the same exponential, so gelu' costs no second transcendental.
 __device__ __forceinline__ void phi_parts(float x, float& cdf, float& ex) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-  ex = __expf(-z * z);  // = e^{-x^2/2}
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float half_erfc = 0.5f * poly * t * ex;     // 0.5 * erfc(|x|/sqrt2)
+  // t = 1 / (1 + p |x| / sqrt2) by a bare v_rcp_f32 (1 ulp; __frcp_rn expands to a 12-instruction IEEE divide)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(x), 1.0f));
+  ex = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // e^{-x^2/2} = 2^{-x^2 log2(e) / 2}
+  float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);  // the 0.5 of 0.5 erfc folded into the coefficients
+  poly = fmaf(poly, t, 0.5f * 1.421413741f);
+  poly = fmaf(poly, t, 0.5f * -0.284496736f);
+  poly = fmaf(poly, t, 0.5f * 0.254829592f);
+  const float half_erfc = poly * t * ex;     // 0.5 * erfc(|x|/sqrt2)
   cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
 __device__ __forceinline__ float gelu_erf(float x) {

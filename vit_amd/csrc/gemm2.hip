@@ -311,75 +311,102 @@ static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hi
 // and, beside LDS-DMA in flight, after ANY load: 32 serialised HBM round trips per tile in the generic epilogue):
 //   3 = (+bias) (+dropout) -> bf16      Y = X W^T of the QKV / attention-output / FC2 projections
 //   4 = +bias, erf-GELU (pre-activation saved to aux_out when given) -> bf16        FC1
-//   5 = * gelu'(aux_in) -> bf16         dX of FC2; the wave's 32 aux rows are fetched in ONE batch up front
+//   5 = * gelu'(aux_in) -> bf16         dX of FC2; the wave's aux rows are fetched in two batches of 8 loads, up front
 //   6 = plain -> bf16                   dX = dY W
 //   7 = plain -> f32 (C or split-K slab)  dW = dY^T X
-// Same per-wave LDS transpose as tile_epilogue: a lane ends up owning 4 consecutive columns of rows rr*4 + lane/16.
+// Same per-wave LDS transpose as tile_epilogue on the way in; on the way out a lane owns 16 bytes of output.
 template <int FAST>
 __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
                                             int lane) {
   const int l15 = lane & 15, lg = lane >> 4;
-  const int n = n0 + l15 * 4;           // this lane's 4 output columns (row-major side)
-  const int rsub = lane >> 4;           // its row inside each group of 4 rows
+  if (FAST == 7) {
+    // f32 out: a lane owns 4 consecutive columns of rows rr*4 + lane/16 (16-byte stores, 256-byte row segments)
+    float* cf = p.splits > 1 ? p.slab + (long)split * p.M * p.N : (float*)p.C;
+    const long ldc = p.splits > 1 ? (long)p.N : p.ldc;
+    const int n = n0 + l15 * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *(f32x4*)(scr + l15 * 256 + (((j * 4 + lg) ^ l15) << 4)) = acc[i][j];
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = rr * 4 + lg;
+        *(f32x4*)(cf + (long)(m0 + i * 16 + row) * ldc + n) = *(const f32x4*)(scr + row * 256 + ((l15 ^ row) << 4));
+      }
+    }
+    return;
+  }
+  // bf16 out: a lane owns 8 consecutive columns of rows rr*8 + lane/8, so every store is 16 bytes per lane and a
+  // wave-instruction covers 8 whole 128-byte row segments (the epilogue is store-ISSUE bound: half as many, twice as wide)
+  const int cg = lane & 7, rsub = lane >> 3;
+  const int n = n0 + cg * 8;
   const unsigned half_cols = (unsigned)(p.N >> 1);
-  f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if ((FAST == 3 || FAST == 4) && p.bias) bv = *(const f32x4*)(p.bias + n);
-  u32x2 au[4][4];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile: 64 aux VGPRs spill)
-  float* cf = (FAST == 7) ? (p.splits > 1 ? p.slab + (long)split * p.M * p.N : (float*)p.C) : nullptr;
-  const long ldc = (FAST == 7 && p.splits > 1) ? (long)p.N : p.ldc;
+  f32x4 bv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
+  if ((FAST == 3 || FAST == 4) && p.bias) {
+    bv0 = *(const f32x4*)(p.bias + n);
+    bv1 = *(const f32x4*)(p.bias + n + 4);
+  }
+  u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (FAST == 5 && (i & 3) == 0) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          au[ii][rr] = *(const u32x2*)(p.aux_in + (long)(m0 + (i + ii) * 16 + rr * 4 + rsub) * p.ldaux + n);
+        for (int rr = 0; rr < 2; ++rr)
+          au[ii][rr] = *(const u32x4*)(p.aux_in + (long)(m0 + (i + ii) * 16 + rr * 8 + rsub) * p.ldaux + n);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c16 = j * 4 + lg;
-      *(f32x4*)(scr + l15 * 256 + ((c16 ^ l15) << 4)) = acc[i][j];
+      *(f32x4*)(scr + l15 * 256 + (((j * 4 + lg) ^ l15) << 4)) = acc[i][j];
       acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 v[4];
+    f32x4 v[2][2];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = rr * 4 + rsub;
-      v[rr] = *(const f32x4*)(scr + row * 256 + ((l15 ^ row) << 4));
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = rr * 8 + rsub;
+      v[rr][0] = *(const f32x4*)(scr + row * 256 + (((2 * cg) ^ row) << 4));
+      v[rr][1] = *(const f32x4*)(scr + row * 256 + (((2 * cg + 1) ^ row) << 4));
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const long m = m0 + i * 16 + rr * 4 + rsub;
-      f32x4 o = v[rr];
-      if (FAST == 7) {
-        *(f32x4*)(cf + m * ldc + n) = o;
-        continue;
+    for (int rr = 0; rr < 2; ++rr) {
+      const long m = m0 + i * 16 + rr * 8 + rsub;
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = v[rr][0][r] + bv0[r];
+        o[4 + r] = v[rr][1][r] + bv1[r];
       }
-      if (FAST == 3 || FAST == 4) o += bv;
       if (FAST == 4) {
         if (p.aux_out) {
-          u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-          *(u32x2*)(p.aux_out + m * p.ldaux + n) = pk;
+          u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+          *(u32x4*)(p.aux_out + m * p.ldaux + n) = pk;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+        for (int r = 0; r < 8; ++r) o[r] = gelu_erf(o[r]);
       }
       if (FAST == 5) {
-        const u32x2 u = au[i & 3][rr];
-        o[0] *= dgelu_erf(__builtin_bit_cast(float, u[0] << 16));
-        o[1] *= dgelu_erf(__builtin_bit_cast(float, u[0] & 0xFFFF0000u));
-        o[2] *= dgelu_erf(__builtin_bit_cast(float, u[1] << 16));
-        o[3] *= dgelu_erf(__builtin_bit_cast(float, u[1] & 0xFFFF0000u));
+        const u32x4 u = au[i & 3][rr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[2 * r] *= dgelu_erf(__builtin_bit_cast(float, u[r] << 16));
+          o[2 * r + 1] *= dgelu_erf(__builtin_bit_cast(float, u[r] & 0xFFFF0000u));
+        }
       }
       if (FAST == 3 && p.drop.thr) {
-        float k0, k1, k2, k3;
-        drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n, k0, k1);
-        drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n + 2, k2, k3);
-        o[0] *= k0; o[1] *= k1; o[2] *= k2; o[3] *= k3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float k0, k1;
+          drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n + 2 * r, k0, k1);
+          o[2 * r] *= k0;
+          o[2 * r + 1] *= k1;
+        }
       }
-      u32x2 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-      *(u32x2*)(p.C + (m * p.ldc + n) * 2) = pk;
+      u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+      *(u32x4*)(p.C + (m * p.ldc + n) * 2) = pk;
     }
   }
 }
@@ -414,6 +441,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   constexpr int RING = 8 * HALF;         // 2 K-tiles x 4 half-tiles
   constexpr int SCR = 4096, CW = 64;     // epilogue scratch per wave
   constexpr int XA0 = 0, XB0 = 1, XB1 = 2, XA1 = 3;
+  // vmcnt budget of the four phases after an epilogue: the usual 8 + the FEWEST vector-memory operations that epilogue
+  // issues per wave (its stores: 16 x 16 B for the bf16 kinds, 32 otherwise) -- a lower bound keeps the wait conservative
+  constexpr int RELAX = 8 + ((EPI >= 3 && EPI <= 6) ? 16 : 32);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -534,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #define PP_STAGE(IT, BASE, HOFF, OFF, X)                                                         \
   if ((IT) < T) {                                                                                \
     issue_half(BASE, HOFF, OFF, IT, X);                                                          \
-    if (relaxed) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");                               \
+    if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAX) : "memory");                    \
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
   } else {                                                                                       \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
