@@ -46,6 +46,7 @@ struct Gemm2Args {
   DropCfg drop;
   int rpb, orb, roff;
   int debug;  // diagnostics only (vit_set_option "gemm_debug"): 1 = no DMA after the prologue, 2 = no MFMA
+  int lin_split;  // ping-pong kernel, split-K with one tile per workgroup: 1-D grid of tiles x splits, XCD-contiguous
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
@@ -451,12 +452,23 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   const int wr = wave >> 2, wc = wave & 3, grp = wr;
   const int l15 = lane & 15, lg = lane >> 4;
 
-  const int split = blockIdx.y;
+  const int ntile = p.tiles_m * p.tiles_n;
+  int split = blockIdx.y, bx = blockIdx.x;
+  if (p.lin_split) {
+    // split-K (dW = dY^T X: K = all tokens, a few dozen output tiles): one (tile, K-slice) per workgroup on a 1-D grid.
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id, so give each XCD a CONTIGUOUS run of the
+    // (slice-major) work list: the ~32 tiles an XCD runs then belong to one or two K-slices and fetch that slice's
+    // tiles_m + tiles_n operand panels once into its L2 instead of once per tile (2 x 32 panels).
+    const int total = ntile * p.splits, lin = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, within = lin >> 3;
+    const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    split = pos / ntile;
+    bx = pos - split * ntile;
+  }
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin) / BK;
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int bx = blockIdx.x, nblk = p.nblk;
+  const int nblk = p.nblk;
   const int my_tiles = (ntile - bx + nblk - 1) / nblk;
   const int T = my_tiles * nk;  // K-tiles this workgroup walks
 
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     const int n_here = min(nblk, ntile - round0);
     const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
     const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    const int t = round0 + pos;
+    const int t = p.lin_split ? bx : round0 + pos;
     tm = t / p.tiles_n;
     tn = t - tm * p.tiles_n;
   };
@@ -744,6 +756,11 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.debug = g_gemm2_debug;
 
   dim3 grid(a.nblk, splits);
+  a.lin_split = 0;
+  if (cfg == 5 && splits > 1 && a.nblk == ntile) {
+    a.lin_split = 1;
+    grid = dim3(ntile * splits, 1);
+  }
   int epi5 = epi;  // ping-pong kernel: the specialised epilogue when the descriptor is one of the five hot kinds
   if (cfg == 5) {
     const bool plain = !a.residual && a.rpb == 0 && d->alpha == 1.0f;
