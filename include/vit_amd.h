@@ -156,6 +156,22 @@ int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtyp
  * x.unfold(1,P,S) (+ zero pad of the ragged tail patch) -> patches [B*N, P] (bf16 or f32)   (tokenization.py:45-49) */
 int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, int B, int L, int P, int S, int N,
                     vit_stream stream);
+/* Training-time noise injection of ViTLModule.training_step (src/vit.py:86-88): out = flux + randn_like(flux) * error *
+ * noise_level over n f32 elements (n % 4 == 0; out may alias flux).  The normal variates come from a counter-based
+ * generator keyed on (seed, element index); the reference's come from torch's generator, whose stream is
+ * implementation-defined, so only the distribution is contractual. */
+int vit_add_noise(vit_handle h, const float* flux, const float* error, float* out, long n, float noise_level,
+                  uint64_t seed, vit_stream stream);
+
+/* Rotary position embedding of ViTSelfAttentionWithRoPE (src/models/vit_with_rope.py:58-60 -> src/models/rope.py:66-131,
+ * model.pos_encoding_type: 'rope'): rotates the query and key thirds of the token-major qkv buffer ([rows, ld >= 3*H*dh],
+ * rows = B*T, position = row % T) in place, pairing element i of a head with element i + dh/2 (_rotate_half).
+ * cos_half / sin_half: f32 [T, dh/2] -- the first half of the reference's cached tables (rope.py:44-56), built on the
+ * host by the reference's own formula.  inverse != 0 rotates by the negative angle: the backward of the rotation,
+ * applied to dq / dk before the projection's weight and input gradients. */
+int vit_rope_qk(vit_handle h, void* qkv, int dtype, const float* cos_half, const float* sin_half, long rows, int T,
+                int H, int dh, long ld, int inverse, vit_stream stream);
+
 /* rows 0 of every sample <- cls_token (embedding.py:87-88); optional "+ position_embeddings" (embedding.py:95-97)
  * and the embedding dropout (embedding.py:100) over the whole [B, T, D] f32 token tensor, in place. */
 int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float* pos, int B, int T, int D,

@@ -116,7 +116,8 @@ def cfg_dict_for(rc: refvit.RefConfig, param: str = "log_g"):
         "model": dict(name="vit", task_type=rc.task_type, image_size=rc.image_size, patch_size=rc.patch_size,
                       hidden_size=rc.hidden_size, num_hidden_layers=rc.num_hidden_layers,
                       num_attention_heads=rc.num_attention_heads, stride_size=rc.stride_size, proj_fn=rc.proj_fn,
-                      num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type),
+                      num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type,
+                      max_position_embeddings=rc.max_position_embeddings, rope_base=rc.rope_base),
         "loss": {"name": rc.loss_name},
         "data": {"param": param},
     }
@@ -241,6 +242,57 @@ def make_one(tag, rc, param, batch, wseed, xseed, full_grads, x_override=None, s
     print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def make_rope():
+    """Rotary position embedding: the reference's RotaryPositionEmbedding (src/models/rope.py) run on
+    random q/k pins the restated tables and rotation bit for bit; the model-level fixture p1 then comes from the
+    restatement with the REFERENCE's module doing the rotation inside it (ViTSelfAttentionWithRoPE subclasses the
+    transformers-4.56 attention class and cannot be constructed against the installed 5.15: SURVEY 8c)."""
+    _import_reference()
+    from src.models.rope import RotaryPositionEmbedding
+
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(77))
+    for tag, (B, H, T, dh, base, maxlen) in dict(a=(2, 3, 37, 16, 10000.0, 512), b=(1, 1, 520, 64, 500.0, 512)).items():
+        q = torch.from_numpy(rng.standard_normal((B, H, T, dh)).astype(np.float32))
+        k = torch.from_numpy(rng.standard_normal((B, H, T, dh)).astype(np.float32))
+        mod = RotaryPositionEmbedding(dim=dh, max_seq_len=maxlen, base=base)
+        qr, kr = mod.forward_qk(q, k)
+        cos, sin = refvit.rope_tables(dh, max(T, maxlen), base)
+        assert torch.equal(cos, mod.cos_cached) and torch.equal(sin, mod.sin_cached)
+        assert torch.equal(refvit.apply_rope(q, cos, sin), qr) and torch.equal(refvit.apply_rope(k, cos, sin), kr)
+        out.update({f"{tag}_q": q.numpy(), f"{tag}_k": k.numpy(), f"{tag}_q_rot": qr.numpy(), f"{tag}_k_rot": kr.numpy(),
+                    f"{tag}_cos": cos[:T].numpy(), f"{tag}_sin": sin[:T].numpy(),
+                    f"{tag}_meta": np.asarray([B, H, T, dh, base, maxlen], np.float64)})
+    print("[rope] restated tables + rotation == reference RotaryPositionEmbedding (bit for bit)")
+
+    # model level: 2 layers, 2 heads of 16, rope_base 1000; the rotation inside the restatement done by the reference module
+    rc = refvit.RefConfig(image_size=640, patch_size=32, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                          stride_size=32, pos_encoding_type="rope", rope_base=1000.0, loss_name="mae")
+    sd = refvit.make_state_dict(rc, 51)
+    flux, _, labels = refvit.make_inputs(rc, 3, 52)
+    mod = RotaryPositionEmbedding(dim=rc.head_dim, max_seq_len=rc.max_position_embeddings, base=rc.rope_base)
+    own = refvit.apply_rope
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    o = refvit.forward(rc, tr.params, flux, labels, output_hidden_states=True, output_attentions=True)
+    o.loss.backward()
+    try:
+        refvit.apply_rope = lambda x, cos, sin: mod(x)
+        with torch.no_grad():
+            o_ref = refvit.forward(rc, sd, flux, labels, output_hidden_states=True, output_attentions=True)
+    finally:
+        refvit.apply_rope = own
+    assert torch.equal(o_ref.logits, o.logits.detach()) and torch.equal(o_ref.attentions[0], o.attentions[0].detach())
+    out.update(dict(p1_flux=flux.numpy(), p1_labels=labels.numpy(), p1_logits=o.logits.detach().numpy(),
+                    p1_loss=np.float32(o.loss.detach()), p1_last=o.last_hidden_state.detach().numpy(),
+                    p1_attn0=o.attentions[0].detach().numpy(), p1_wseed=np.int64(51)))
+    for k, p in tr.params.items():
+        if p.grad is not None:
+            out[f"p1_grad/{k}"] = p.grad.detach().numpy()
+    path = os.path.join(ROOT, "tests", "golden", "rope.npz")
+    np.savez_compressed(path, **out)
+    print(f"[rope] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -260,6 +312,7 @@ def main():
     k1 = refvit.RefConfig(image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
                           stride_size=32, task_type="cls", num_labels=5, pos_encoding_type="learned", loss_name="ce")
     make_one("k1", k1, "log_g", 6, 41, 42, True)
+    make_rope()
 
 
 if __name__ == "__main__":

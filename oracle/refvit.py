@@ -47,6 +47,8 @@ class RefConfig:
     task_type: str = "reg"
     num_labels: int = 1
     pos_encoding_type: Optional[str] = None
+    max_position_embeddings: int = 512  # builder.py:231, 256
+    rope_base: float = 10000.0          # builder.py:232, 257
     hidden_dropout_prob: float = 0.1
     attention_probs_dropout_prob: float = 0.1
     layer_norm_eps: float = 1e-12
@@ -112,6 +114,8 @@ def config_from_dict(config: dict) -> RefConfig:
         task_type=m["task_type"],
         num_labels=num_labels,
         pos_encoding_type=m.get("pos_encoding_type", None),
+        max_position_embeddings=m.get("max_position_embeddings", 512),
+        rope_base=m.get("rope_base", 10000.0),
         loss_name=(config.get("loss", {}) or {}).get("name", None) or "",
     )
 
@@ -211,6 +215,30 @@ def make_inputs(cfg: RefConfig, batch: int, seed: int):
     return flux, error, labels
 
 
+# --------------------------------------------------------------------------- rotary position embedding
+def rope_tables(dim: int, seq_len: int, base: float = 10000.0):
+    """RotaryPositionEmbedding.__init__/_precompute_freqs (src/models/rope.py:36-56): cos/sin of
+    outer(arange(seq_len), 1 / base**(arange(0, dim, 2)/dim)), the half-width table repeated twice along the last dim."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    t = torch.arange(seq_len).type_as(inv_freq)
+    freqs = torch.outer(t, inv_freq)
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """rope.py:58-64: [x1, x2] -> [-x2, x1] over the two halves of the last dim."""
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat([-x2, x1], dim=-1)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """rope.py:66-98 for the 4-D (batch, heads, seq, head_dim) case used by the attention (vit_with_rope.py:58-60)."""
+    T = x.shape[2]
+    c, s_ = cos[:T, :].unsqueeze(0).unsqueeze(0), sin[:T, :].unsqueeze(0).unsqueeze(0)
+    return (x * c) + (rotate_half(x) * s_)
+
+
 # --------------------------------------------------------------------------- forward
 @dataclass
 class RefOutput:
@@ -269,13 +297,16 @@ def forward(
         h = h + sd["vit.embeddings.position_embeddings"]
     elif cfg.pos_encoding_type not in (None, "none", "rope"):
         raise ValueError(f"Unsupported pos_encoding_type '{cfg.pos_encoding_type}'")
-    if cfg.pos_encoding_type == "rope":
-        raise NotImplementedError("rope is a SURVEY section 8(f) 'next' row")
     h = drop(h, ph)
 
     hs = [h] if output_hidden_states else None
     atts = [] if output_attentions else None
     T = h.size(1)
+    rope = None
+    if cfg.pos_encoding_type == "rope":
+        # ViTSelfAttentionWithRoPE.__init__ (vit_with_rope.py:26-39): per-head tables of max_position_embeddings rows,
+        # re-computed by the same formula when the sequence is longer (rope.py:110-112)
+        rope = rope_tables(dh, max(T, cfg.max_position_embeddings), cfg.rope_base)
     for i in range(cfg.num_hidden_layers):
         pre = f"vit.encoder.layer.{i}."
         res = h
@@ -286,6 +317,8 @@ def forward(
         q = q.view(B, T, H, dh).transpose(1, 2)
         k = k.view(B, T, H, dh).transpose(1, 2)
         v = v.view(B, T, H, dh).transpose(1, 2)
+        if rope is not None:  # vit_with_rope.py:58-60 -> rope.py:116-131
+            q, k = apply_rope(q, *rope), apply_rope(k, *rope)
         # vit_with_rope.py:63-71 (the in-repo statement of the eager arithmetic); there is no logit clamp
         scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
         probs = F.softmax(scores, dim=-1)

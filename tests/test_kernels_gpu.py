@@ -546,3 +546,23 @@ def test_attention_f32(dev, B, H, T, dh):
         assert rel(ctxd, refd) < 1e-5
         refd.backward(dctx)
         assert rel(vf.attention_bwd(qkv, ctxd, dctx, lsed, B, H, T, dh, scale, dropout=drop), q32.grad) < 2e-5
+
+
+def test_add_noise_distribution(dev):
+    """vit_add_noise (vit.py:86-88): out - flux = z * error * level with z ~ N(0,1): moments, tails, independence of the
+    launch geometry (same seed -> same noise), different seeds decorrelated."""
+    import vit_amd.functional as vf
+
+    n = 1 << 22
+    flux, err = randn((n,), dev, 100), torch.rand(n, device=dev) * 0.2 + 0.05
+    out = vf.add_noise(flux, err, 0.5, seed=1234)
+    z = ((out - flux) / (err * 0.5)).double()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.var()) - 1.0) < 5e-3
+    assert abs(float((z ** 3).mean())) < 2e-2 and abs(float((z ** 4).mean()) - 3.0) < 5e-2
+    assert abs(float((z.abs() > 1.959964).double().mean()) - 0.05) < 1e-3
+    assert torch.equal(vf.add_noise(flux, err, 0.5, seed=1234), out)
+    z2 = ((vf.add_noise(flux, err, 0.5, seed=1235) - flux) / (err * 0.5)).double()
+    assert abs(float((z * z2).mean())) < 3e-3 and abs(float((z[:-1] * z[1:]).mean())) < 3e-3
+    # a 2-D batch of the reference's shape, level 0 is the identity
+    f2, e2 = flux[: 64 * 4096].view(64, 4096), err[: 64 * 4096].view(64, 4096)
+    assert torch.equal(vf.add_noise(f2, e2, 0.0, seed=1), f2)

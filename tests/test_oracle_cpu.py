@@ -162,3 +162,29 @@ def test_optmodule_mirrors_reference_config_handling():
     assert isinstance(conf2["lr_scheduler"]["scheduler"], torch.optim.lr_scheduler.SequentialLR)
     with pytest.raises(ValueError):
         OptModule(lr=1e-3, lr_scheduler_name="nope")(lin)
+
+
+def test_oracle_rope_matches_reference_module():
+    """rope.npz was written by oracle/make_golden.py from the reference's RotaryPositionEmbedding (src/models/rope.py):
+    the restated tables and rotation must reproduce it bit for bit, including a sequence longer than the 512-row cache."""
+    g = np.load(os.path.join(GOLD, "rope.npz"))
+    for tag in ("a", "b"):
+        B, H, T, dh, base, maxlen = g[f"{tag}_meta"]
+        T, dh = int(T), int(dh)
+        cos, sin = refvit.rope_tables(dh, max(T, int(maxlen)), float(base))
+        assert np.array_equal(cos[:T].numpy(), g[f"{tag}_cos"]) and np.array_equal(sin[:T].numpy(), g[f"{tag}_sin"])
+        for n in ("q", "k"):
+            out = refvit.apply_rope(torch.from_numpy(g[f"{tag}_{n}"]), cos, sin)
+            assert np.array_equal(out.numpy(), g[f"{tag}_{n}_rot"])
+    # model level (2 layers, rope_base 1000): the fixture is the restatement with the reference module doing the rotation
+    rc = refvit.RefConfig(image_size=640, patch_size=32, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                          stride_size=32, pos_encoding_type="rope", rope_base=1000.0, loss_name="mae")
+    sd = refvit.make_state_dict(rc, int(g["p1_wseed"]))
+    with torch.no_grad():
+        out = refvit.forward(rc, sd, torch.from_numpy(g["p1_flux"]), torch.from_numpy(g["p1_labels"]), output_attentions=True)
+    assert rel(out.logits, g["p1_logits"]) < 1e-6 and rel(out.attentions[0], g["p1_attn0"]) < 1e-6
+    # without the rotation the outputs differ: the fixture really exercises it
+    rc0 = refvit.RefConfig(**{**rc.__dict__, "pos_encoding_type": None})
+    with torch.no_grad():
+        out0 = refvit.forward(rc0, sd, torch.from_numpy(g["p1_flux"]), torch.from_numpy(g["p1_labels"]))
+    assert rel(out0.logits, g["p1_logits"]) > 1e-3

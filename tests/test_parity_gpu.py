@@ -305,3 +305,85 @@ def test_f32_mode_train_step_runs_with_dropout(dev):
     l1 = model(x, labels=labels).loss
     l1.backward()
     assert torch.isfinite(l1) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+# ------------------------------------------------------------------ rotary position embedding
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_rope_kernel_matches_reference_vectors(dev, dt):
+    """vit_rope_qk on the reference's own vectors (tests/golden/rope.npz: RotaryPositionEmbedding.forward_qk outputs);
+    f32: <= 1 ulp-level (the kernel evaluates x*cos - x2*sin with FMAs), bf16: one rounding of the result."""
+    import vit_amd.functional as vf
+
+    g = np.load(os.path.join(GOLD, "rope.npz"))
+    for tag in ("a", "b"):
+        B, H, T, dh, base, maxlen = (int(v) if i < 4 else float(v) for i, v in enumerate(g[f"{tag}_meta"]))
+        q, k = torch.from_numpy(g[f"{tag}_q"]), torch.from_numpy(g[f"{tag}_k"])
+        v = torch.randn(B, H, T, dh)
+        tok = lambda t: t.transpose(1, 2).reshape(B * T, H * dh)          # [B,H,T,dh] -> token-major [B*T, H*dh]
+        qkv = torch.cat([tok(q), tok(k), tok(v)], dim=1).to(dt).to(dev).contiguous()
+        cos = torch.from_numpy(g[f"{tag}_cos"])[:, : dh // 2].contiguous().to(dev)
+        sin = torch.from_numpy(g[f"{tag}_sin"])[:, : dh // 2].contiguous().to(dev)
+        before = qkv.clone()
+        vf.rope_qk(qkv, cos, sin, T, H, dh)
+        D = H * dh
+        tol = 2e-7 if dt == torch.float32 else 4e-3
+        if dt == torch.bfloat16:  # the kernel rotates the bf16-rounded inputs
+            from oracle import refvit
+            c_full, s_full = torch.from_numpy(g[f"{tag}_cos"]), torch.from_numpy(g[f"{tag}_sin"])
+            ref_q = refvit.apply_rope(q.to(dt).float(), c_full, s_full)
+            ref_k = refvit.apply_rope(k.to(dt).float(), c_full, s_full)
+        else:
+            ref_q, ref_k = torch.from_numpy(g[f"{tag}_q_rot"]), torch.from_numpy(g[f"{tag}_k_rot"])
+        assert rel(qkv[:, :D].float(), tok(ref_q)) < tol
+        assert rel(qkv[:, D:2 * D].float(), tok(ref_k)) < tol
+        assert torch.equal(qkv[:, 2 * D:], before[:, 2 * D:])              # v untouched
+        vf.rope_qk(qkv, cos, sin, T, H, dh, inverse=True)                   # rotation by -angle undoes it
+        assert rel(qkv.float(), before.float()) < (5e-7 if dt == torch.float32 else 6e-3)
+
+
+@pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
+def test_rope_model_matches_oracle(dev, precision):
+    """Full model with pos_encoding_type='rope' (vit_with_rope.py:58-60) against the p1 fixture (the restatement with
+    the reference's RotaryPositionEmbedding doing the rotation): logits, first attention map, loss, every gradient."""
+    from oracle import refvit
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    g = np.load(os.path.join(GOLD, "rope.npz"))
+    rc = refvit.RefConfig(image_size=640, patch_size=32, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                          stride_size=32, pos_encoding_type="rope", rope_base=1000.0, loss_name="mae")
+    sd = refvit.make_state_dict(rc, int(g["p1_wseed"]))
+    cfg = ViTConfig(task_type="reg", image_size=640, patch_size=32, hidden_size=32, num_hidden_layers=2,
+                    num_attention_heads=2, stride_size=32, pos_encoding_type="rope", rope_base=1000.0)
+    model = MyViT(cfg, loss_name="mae")
+    model.set_precision(precision)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    x, labels = torch.from_numpy(g["p1_flux"]).to(dev), torch.from_numpy(g["p1_labels"]).to(dev)
+    out = model(x, labels=labels, output_attentions=True)
+    tight = precision == "32"
+    assert rel(out.logits, torch.from_numpy(g["p1_logits"])) < (1e-4 if tight else 1.5e-2)
+    assert rel(out.attentions[0], torch.from_numpy(g["p1_attn0"])) < (1e-4 if tight else 1.5e-2)
+    # MSE loss: d(loss) = 2 * residual * d(logit); residual ~ sqrt(loss) = 0.26, logits ~ 1 with bf16 error <= 1.5e-2
+    loss_tol = 1e-4 * float(g["p1_loss"]) if tight else 2 * float(g["p1_loss"]) ** 0.5 * 1.5e-2
+    assert abs(float(out.loss) - float(g["p1_loss"])) <= loss_tol + 1e-6
+    model(x, labels=labels).loss.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        k = f"p1_grad/{name}"
+        if k not in g.files:
+            continue
+        ref = torch.from_numpy(g[k])
+        if float(ref.norm()) < 1e-6:
+            continue
+        assert p.grad is not None, name
+        mine = p.grad.reshape(ref.shape).cpu()
+        if tight:
+            assert rel(mine, ref) < 2e-4, name
+        else:
+            # every gradient scales with dL/dlogit = 2 (logit - label) / n, whose own bf16 error is d(logit) / residual
+            # = 1.5e-2 / 0.26 ~ 6 % on this fixture: bound the direction tightly and the magnitude by that
+            cos = float(torch.dot(mine.flatten().double(), ref.flatten().double()) / (mine.double().norm() * ref.double().norm()))
+            assert cos > 0.999 and rel(mine, ref) < 8e-2, (name, cos, rel(mine, ref))
+        checked += 1
+    assert checked > 20

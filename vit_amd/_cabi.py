@@ -66,6 +66,8 @@ _PROTOS = {
     "vit_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
     "vit_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vit_unfold_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vit_add_noise": [_P, _P, _P, _P, C.c_long, _F, _U64, _P],
+    "vit_rope_qk": [_P, _P, _I, _P, _P, C.c_long, _I, _I, _I, C.c_long, _I, _P],
     "vit_embed_finish": [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],
     "vit_embed_finish_bwd": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _U64, _U64, _I, _P],
     "vit_dropout_bwd_cast": [_P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],

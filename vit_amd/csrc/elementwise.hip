@@ -367,6 +367,74 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// ---- training-time noise injection (ViTLModule.training_step, src/vit.py:86-88): out = flux + N(0,1) * error * level.
+// The reference draws from torch's generator (implementation-defined stream); here a counter-based generator keyed on
+// (seed, element index): two 32-bit hashes -> Box-Muller pair, 4 elements per work item, so the noise is reproducible
+// for a given seed and independent of the launch geometry.
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ flux, const float* __restrict__ error,
+                                                        float* __restrict__ out, long nvec, float level, unsigned k0,
+                                                        unsigned k1) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 f = *(const f32x4*)(flux + 4 * i), e = *(const f32x4*)(error + 4 * i);
+    f32x4 z;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const unsigned h1 = drop_hash(k0, k1, (unsigned long long)(4 * i + 2 * p));
+      const unsigned h2 = drop_hash(k0, k1, (unsigned long long)(4 * i + 2 * p + 1));
+      const float u1 = ((float)(h1 >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+      const float u2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);            // [0, 1)
+      const float r = sqrtf(-2.0f * __logf(u1));
+      float sn, cs;
+      __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+      z[2 * p] = r * cs;
+      z[2 * p + 1] = r * sn;
+    }
+    *(f32x4*)(out + 4 * i) = f + z * e * level;
+  }
+}
+
+// ---- rotary position embedding on the q and k thirds of the token-major qkv buffer, in place (rope.py:66-98 with
+// _rotate_half: element i of a head pairs with element i + dh/2).  cos/sin: f32 [T, dh/2] (the reference's cached table
+// is this half-width table twice along the last dim).  One work item = 4 pairs of one (row, q|k, head): 16-byte loads
+// of both halves.  inverse: rotate by -angle, i.e. the backward of the forward rotation (a rotation's transpose).
+template <int BF16>
+__global__ __launch_bounds__(256) void rope_qk_kernel(void* __restrict__ qkv, const float* __restrict__ cs,
+                                                      const float* __restrict__ sn, long rows, int T, int H, int dh,
+                                                      long ld, float sign) {
+  const int hv = dh >> 3;                 // vectors of 4 pairs per head
+  const long per_row = 2L * H * hv;
+  const long total = rows * per_row;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / per_row;
+    const int rem = (int)(idx - row * per_row);
+    const int which = rem / (H * hv), r2 = rem - which * (H * hv);
+    const int head = r2 / hv, v = r2 - head * hv;
+    const int t = (int)(row % T);
+    const f32x4 c = *(const f32x4*)(cs + (long)t * (dh >> 1) + 4 * v);
+    const f32x4 s = *(const f32x4*)(sn + (long)t * (dh >> 1) + 4 * v) * sign;
+    const long off = row * ld + (long)which * H * dh + (long)head * dh + 4 * v;
+    f32x4 x1, x2;
+    if (BF16) {
+      const bf16x4 a = *(const bf16x4*)((const short*)qkv + off);
+      const bf16x4 b = *(const bf16x4*)((const short*)qkv + off + (dh >> 1));
+      x1 = (f32x4){bf2f(a[0]), bf2f(a[1]), bf2f(a[2]), bf2f(a[3])};
+      x2 = (f32x4){bf2f(b[0]), bf2f(b[1]), bf2f(b[2]), bf2f(b[3])};
+    } else {
+      x1 = *(const f32x4*)((const float*)qkv + off);
+      x2 = *(const f32x4*)((const float*)qkv + off + (dh >> 1));
+    }
+    const f32x4 o1 = x1 * c - x2 * s;   // x * cos + rotate_half(x) * sin, first half: rotate_half = -x2
+    const f32x4 o2 = x2 * c + x1 * s;   //                                 second half: rotate_half = +x1
+    if (BF16) {
+      *(u32x2*)((short*)qkv + off) = (u32x2){pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
+      *(u32x2*)((short*)qkv + off + (dh >> 1)) = (u32x2){pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
+    } else {
+      *(f32x4*)((float*)qkv + off) = o1;
+      *(f32x4*)((float*)qkv + off + (dh >> 1)) = o2;
+    }
+  }
+}
+
 }  // namespace vit
 
 extern "C" {
@@ -384,6 +452,37 @@ int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, 
     hipLaunchKernelGGL(unfold_cast_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, L, P, S, N);
   else
     hipLaunchKernelGGL(unfold_cast_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, patches, B, L, P, S, N);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_add_noise(vit_handle h, const float* flux, const float* error, float* out, long n, float noise_level,
+                  uint64_t seed, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(flux && error && out, VIT_ERR_ARG, "vit_add_noise: null pointer");
+  VIT_CHECK(n > 0 && (n % 4) == 0, VIT_ERR_ARG, "vit_add_noise: n=%ld must be a positive multiple of 4", n);
+  const DropCfg d = make_drop(0.f, seed, 0x6e6f697365ull /* "noise" */);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, flux, error, out, n / 4,
+                     noise_level, d.k0, d.k1);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_rope_qk(vit_handle h, void* qkv, int dtype, const float* cos_half, const float* sin_half, long rows, int T,
+                int H, int dh, long ld, int inverse, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(qkv && cos_half && sin_half, VIT_ERR_ARG, "vit_rope_qk: null pointer");
+  VIT_CHECK(rows > 0 && T > 0 && H > 0 && dh > 0 && (dh % 8) == 0 && ld >= 3L * H * dh && (ld % 4) == 0, VIT_ERR_ARG,
+            "vit_rope_qk: rows=%ld T=%d H=%d dh=%d ld=%ld (head_dim must be a multiple of 8)", rows, T, H, dh, ld);
+  VIT_CHECK(dtype == VIT_BF16 || dtype == VIT_F32, VIT_ERR_ARG, "vit_rope_qk: bad dtype");
+  const long total = rows * 2L * H * (dh >> 3);
+  const float sign = inverse ? -1.f : 1.f;
+  if (dtype == VIT_BF16)
+    hipLaunchKernelGGL(rope_qk_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, qkv, cos_half, sin_half,
+                       rows, T, H, dh, ld, sign);
+  else
+    hipLaunchKernelGGL(rope_qk_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, qkv, cos_half, sin_half,
+                       rows, T, H, dh, ld, sign);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

@@ -127,9 +127,10 @@ class ParamLayout:
 
 class ViTEngine:
     def __init__(self, cfg: ViTConfig, loss_name: str = ""):
-        if cfg.pos_encoding_type == "rope":
-            raise NotImplementedError("pos_encoding_type='rope' is a SURVEY section 8(f) 'next' row")
-        if cfg.pos_encoding_type not in (None, "none", "learned"):
+        if cfg.pos_encoding_type == "rope" and (cfg.head_dim % 8) != 0:
+            raise ValueError(f"pos_encoding_type='rope' needs head_dim % 8 == 0 here (got {cfg.head_dim}); "
+                             f"the reference needs it even (rope.py:28-29)")
+        if cfg.pos_encoding_type not in (None, "none", "learned", "rope"):
             raise ValueError(f"Unsupported pos_encoding_type '{cfg.pos_encoding_type}'. "
                              f"Choose from: 'rope', 'learned', 'none', or None")  # embedding.py:74
         if cfg.proj_fn not in ("SW", "C1D", "CNN"):
@@ -277,6 +278,19 @@ class ViTEngine:
             )
         self._arena_key = key
 
+    def _rope_tables(self, T: int):
+        """Half-width cos / sin tables of RotaryPositionEmbedding (rope.py:36-56), computed on the host by the reference's
+        own expression (so the table bits are the reference's) and kept on the device."""
+        c = self.cfg
+        key = (T, c.head_dim, float(c.rope_base), self.flat.device)
+        if getattr(self, "_rope_key", None) != key:
+            dim = c.head_dim
+            inv_freq = 1.0 / (c.rope_base ** (torch.arange(0, dim, 2).float() / dim))
+            freqs = torch.outer(torch.arange(T).type_as(inv_freq), inv_freq)
+            self._rope = (freqs.cos().contiguous().to(self.flat.device), freqs.sin().contiguous().to(self.flat.device))
+            self._rope_key = key
+        return self._rope
+
     # ------------------------------------------------------------------ forward
     def _site(self, layer: int, which: int) -> int:
         return 1 + 4 * layer + which
@@ -315,6 +329,7 @@ class ViTEngine:
         vf.embed_finish(x0, self.p(e + "cls_token").view(D), pos, dropout=(ph, seed, 0))
 
         atts = [] if output_attentions else None
+        rope = self._rope_tables(T) if c.pos_encoding_type == "rope" else None
         # The two "dropout(Linear(.)) + residual" sums of a layer (HF ViTLayer / ViTOutput) are formed by the LayerNorm
         # that consumes them: the projection GEMM writes y = dropout(acc + bias) in the activation dtype, the LayerNorm
         # pass reads the f32 stream and y, writes the new stream and its normalised operand (vit_layernorm_fwd_residual).
@@ -328,6 +343,8 @@ class ViTEngine:
             else:
                 self._ln_res(a["x1"][jprev], y, xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
             vf.gemm(a["h1"][j], self._qkv16(i), M=M, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
+            if rope is not None:  # vit_with_rope.py:58-60: q, k rotated per head before the scores
+                vf.rope_qk(a["qkv"][j], rope[0], rope[1], T, H, dh)
             vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
                              lse=a["lse"][j])
             if output_attentions:
@@ -379,6 +396,7 @@ class ViTEngine:
             c.num_hidden_layers, c.num_patches, c.patch_size
         dh, M = c.head_dim, B * T
         scale = dh ** -0.5
+        rope = self._rope_tables(T) if c.pos_encoding_type == "rope" else None
         cb = self.grad_ready_cb
         hn = self.layout.head
         dloss = dloss.reshape(1).to(torch.float32).contiguous()
@@ -416,6 +434,8 @@ class ViTEngine:
             vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, b_trans=True, out=t["dctx"])
             vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
                              dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"])
+            if rope is not None:  # gradient wrt the un-rotated q, k: the inverse rotation
+                vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
             vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
             vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=M, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
                     split_k=-1)

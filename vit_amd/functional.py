@@ -195,6 +195,33 @@ def attention_probs(qkv, B: int, H: int, T: int, dh: int, scale: float):
 
 
 # ------------------------------------------------------------------------------------------------ embedding side
+def add_noise(flux, error, noise_level: float, seed: int, out=None):
+    """flux + N(0,1) * error * noise_level (vit.py:86-88), counter-based normals keyed on (seed, element index)."""
+    _chk(flux, torch.float32, "add_noise flux")
+    _chk(error, torch.float32, "add_noise error")
+    if error.shape != flux.shape or flux.numel() % 4:
+        raise _cabi.VitError("add_noise: flux/error must have the same shape and a multiple of 4 elements")
+    out = out if out is not None else torch.empty_like(flux)
+    h = _h(flux)
+    check(h.lib.vit_add_noise(h.h, flux.data_ptr(), error.data_ptr(), out.data_ptr(), flux.numel(), float(noise_level),
+                              int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(flux)), "vit_add_noise")
+    return out
+
+
+def rope_qk(qkv, cos_half, sin_half, T: int, H: int, dh: int, inverse: bool = False):
+    """In-place rotary embedding of the q and k thirds of qkv [B*T, 3*H*dh] (bf16 or f32); cos/sin f32 [>=T, dh/2]."""
+    if qkv.dtype not in _DT or not qkv.is_contiguous() or qkv.dim() != 2 or qkv.shape[1] != 3 * H * dh:
+        raise _cabi.VitError(f"rope_qk: qkv must be a contiguous [rows, {3 * H * dh}] bf16/f32 tensor")
+    _chk(cos_half, torch.float32, "rope_qk cos")
+    _chk(sin_half, torch.float32, "rope_qk sin")
+    if cos_half.shape[-1] != dh // 2 or cos_half.shape[0] < T or sin_half.shape != cos_half.shape:
+        raise _cabi.VitError("rope_qk: tables must be [>= T, dh/2]")
+    h = _h(qkv)
+    check(h.lib.vit_rope_qk(h.h, qkv.data_ptr(), _DT[qkv.dtype], cos_half.data_ptr(), sin_half.data_ptr(), qkv.shape[0], T,
+                            H, dh, qkv.shape[1], 1 if inverse else 0, _stream(qkv)), "vit_rope_qk")
+    return qkv
+
+
 def unfold_cast(x, P: int, S: int, N: int, out=None, out_dtype=torch.bfloat16):
     _chk(x, torch.float32, "unfold_cast x")
     h = _h(x)

@@ -173,7 +173,15 @@ class ViTLModule(BaseLightningModule):
     def training_step(self, batch, batch_idx):
         flux, error, labels = batch
         if self.noise_level > 0:
-            noisy = flux + torch.randn_like(flux) * error * self.noise_level
+            # vit.py:86-88; on the device through vit_add_noise (no arithmetic of the path runs in torch), one fresh
+            # seed per step drawn from torch's seeded CPU generator so that seed_everything(42) fixes the whole run
+            if flux.is_cuda:
+                from . import functional as vf
+
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                noisy = vf.add_noise(flux.contiguous().float(), error.contiguous().float(), self.noise_level, seed)
+            else:
+                noisy = flux + torch.randn_like(flux) * error * self.noise_level
             loss = self(noisy, labels, loss_only=True)
         else:
             loss = self(flux, labels, loss_only=True)
