@@ -87,6 +87,8 @@ typedef struct vit_gemm_desc {
   int rows_per_batch, out_batch_rows, out_row_offset;
   int split_k;             /* 0/1 = off; >1 = that many K slices; -1 = choose */
   int accumulate;          /* split_k path: C += result instead of C = result */
+  float* colsum_out;       /* optional f32 [N]: column sums of C as stored (a Linear's bias gradient when C is the gradient
+                            * of its output); summed inside the epilogue where the kernel can, else by a vit_colsum pass */
 } vit_gemm_desc;
 int vit_gemm(vit_handle h, const vit_gemm_desc* d, vit_stream stream);
 /* Symbol (as rocprofv3 prints it, without the "void vit::" prefix and argument list) of the kernel the calling thread's

@@ -566,3 +566,28 @@ def test_add_noise_distribution(dev):
     # a 2-D batch of the reference's shape, level 0 is the identity
     f2, e2 = flux[: 64 * 4096].view(64, 4096), err[: 64 * 4096].view(64, 4096)
     assert torch.equal(vf.add_noise(f2, e2, 0.0, seed=1), f2)
+
+
+@pytest.mark.parametrize("core", [0, 1])
+def test_gemm_colsum_out(dev, core):
+    """colsum_out = column sums of the stored C (a bias gradient): fused in the ping-pong epilogue (core 1 = automatic on a
+    256-aligned problem) or computed by the fallback pass (core 0); both must equal vit_colsum of the output."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+    from vit_amd._cabi import ACT_DGELU
+
+    M, N, K = 256 * 5, 768, 256
+    dy, W, u = bf(randn((M, K), dev, 110)), bf(randn((K, N), dev, 111, 0.1)), bf(randn((M, N), dev, 112))
+    _cabi.set_option("gemm_core", core)
+    try:
+        cs = torch.empty(N, device=dev)
+        out = vf.gemm(dy, W, M=M, N=N, K=K, b_trans=True, act=ACT_DGELU, aux_in=u, colsum_out=cs)   # dX * gelu'(u)
+        assert rel(cs, out.float().sum(0)) < 1e-5
+        cs2 = torch.empty(N, device=dev)
+        out2 = vf.gemm(dy, W, M=M, N=N, K=K, b_trans=True, colsum_out=cs2)                           # plain dX
+        assert rel(cs2, out2.float().sum(0)) < 1e-5
+        again = torch.empty(N, device=dev)
+        vf.gemm(dy, W, M=M, N=N, K=K, b_trans=True, colsum_out=again)
+        assert torch.equal(again, cs2)  # deterministic
+    finally:
+        _cabi.set_option("gemm_core", 1)

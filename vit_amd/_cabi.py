@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("rows_per_batch", C.c_int), ("out_batch_rows", C.c_int), ("out_row_offset", C.c_int),
         ("split_k", C.c_int),
         ("accumulate", C.c_int),
+        ("colsum_out", C.c_void_p),
     ]
 
 

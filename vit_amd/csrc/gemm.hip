@@ -461,7 +461,18 @@ int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, in
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+thread_local int g_colsum_fused = 0;  // set by a core whose epilogue produced d->colsum_out itself
+static int gemm_launch_core(vit_handle h, const vit_gemm_desc* d, hipStream_t st);
+
 int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
+  g_colsum_fused = 0;
+  const int rc = gemm_launch_core(h, d, st);
+  if (rc != VIT_OK || !d->colsum_out || g_colsum_fused) return rc;
+  VIT_CHECK(d->rows_per_batch == 0, VIT_ERR_ARG, "vit_gemm: colsum_out with a row map is not supported");
+  return vit_colsum(h, d->C, d->c_dtype, d->ldc, d->colsum_out, d->M, d->N, 0, (vit_stream)st);
+}
+
+static int gemm_launch_core(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   VIT_CHECK(d && d->A && d->B && d->C, VIT_ERR_ARG, "vit_gemm: null operand");
   VIT_CHECK(d->M > 0 && d->N > 0 && d->K > 0, VIT_ERR_ARG, "vit_gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
   VIT_CHECK(d->ab_dtype == VIT_BF16 || d->ab_dtype == VIT_F32, VIT_ERR_ARG, "vit_gemm: bad ab_dtype");

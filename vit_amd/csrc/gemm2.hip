@@ -47,6 +47,7 @@ struct Gemm2Args {
   int rpb, orb, roff;
   int debug;  // diagnostics only (vit_set_option "gemm_debug"): 1 = no DMA after the prologue, 2 = no MFMA
   int lin_split;  // ping-pong kernel, split-K with one tile per workgroup: 1-D grid of tiles x splits, XCD-contiguous
+  float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
@@ -350,6 +351,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
     bv0 = *(const f32x4*)(p.bias + n);
     bv1 = *(const f32x4*)(p.bias + n + 4);
   }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // column sums of the stored (bf16-rounded) values
   u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -408,6 +410,28 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
       }
       u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
       *(u32x4*)(p.C + (m * p.ldc + n) * 2) = pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cs[2 * r] += __builtin_bit_cast(float, pk[r] << 16);
+        cs[2 * r + 1] += __builtin_bit_cast(float, pk[r] & 0xFFFF0000u);
+      }
+    }
+  }
+  if (p.colsum_part) {
+    // the 8 lanes with the same lane & 7 hold the same 8 columns over different rows: fold them, lanes 0-7 store the
+    // wave's 128-row sums; the two wave rows of a tile write separate partial rows (fixed order -> deterministic)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float v = cs[r];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      cs[r] = v;
+    }
+    if (lane < 8) {
+      float* dst = p.colsum_part + (long)(m0 >> 7) * p.N + n;
+      *(f32x4*)dst = (f32x4){cs[0], cs[1], cs[2], cs[3]};
+      *(f32x4*)(dst + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
     }
   }
 }
@@ -674,6 +698,7 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
   return launch_stag<1, 1, 0>(a, grid, st);
 }
 
+extern thread_local int g_colsum_fused;  // gemm.hip
 int g_gemm2_mode = -1;  // -1: read VIT_GEMM2 from the environment on first use
 int g_gemm2_debug = 0;
 
@@ -757,6 +782,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
 
   dim3 grid(a.nblk, splits);
   a.lin_split = 0;
+  a.colsum_part = nullptr;
   if (cfg == 5 && splits > 1 && a.nblk == ntile) {
     a.lin_split = 1;
     grid = dim3(ntile * splits, 1);
@@ -771,6 +797,11 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
              splits == 1) epi5 = 6;
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_F32 && d->a_trans && d->b_trans) epi5 = 7;
   }
+  if (d->colsum_out && cfg == 5 && (epi5 == 3 || epi5 == 5 || epi5 == 6)) {
+    size_t wsb = 0;
+    void* ws = ctx_workspace(h, &wsb);
+    if (ws && wsb >= (size_t)a.tiles_m * 2 * d->N * sizeof(float)) a.colsum_part = (float*)ws;
+  }
   {
     static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
@@ -784,6 +815,10 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
   else if (cfg == 6) r = launch_cfg<256, 128, 32, 3, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
   else r = launch_cfg<256, 256, 32, 4, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
+  if (r == VIT_OK && a.colsum_part) {
+    r = launch_reduce_partials(a.colsum_part, a.tiles_m * 2, d->N, d->colsum_out, d->N, d->colsum_out, 0, st);
+    g_colsum_fused = 1;
+  }
   if (r == VIT_OK && splits > 1)
     r = launch_splitk_reduce(a.slab, (float*)d->C, (long)d->ldc, d->M, d->N, splits, d->alpha, d->accumulate, st);
   *rc = r;

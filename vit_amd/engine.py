@@ -418,8 +418,7 @@ class ViTEngine:
             vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=M, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
                     split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=M, N=Fd, K=D, b_trans=True, out=t["dU"],
-                    act=vf.ACT_DGELU, aux_in=a["u"][i])
-            vf.colsum(t["dU"], out=self.g(pre + "intermediate.dense.bias"))
+                    act=vf.ACT_DGELU, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
             vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=M, a_trans=True, b_trans=True,
                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
             vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=M, N=D, K=Fd, b_trans=True, out=t["dh"])

@@ -44,7 +44,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
          out_dtype=torch.bfloat16, ldc: Optional[int] = None, alpha: float = 1.0, bias: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, aux_out: Optional[torch.Tensor] = None, aux_in: Optional[torch.Tensor] = None,
          dropout: Dropout = NO_DROP, residual: Optional[torch.Tensor] = None, row_map: Tuple[int, int, int] = (0, 0, 0),
-         out_rows: Optional[int] = None, split_k: int = 0, accumulate: bool = False) -> torch.Tensor:
+         out_rows: Optional[int] = None, split_k: int = 0, accumulate: bool = False,
+         colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     h = _h(a)
     if a.dtype != b.dtype or a.dtype not in _DT:
         raise _cabi.VitError(f"gemm: operands must both be bf16 or both f32 (got {a.dtype}, {b.dtype})")
@@ -66,6 +67,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
     d.rows_per_batch, d.out_batch_rows, d.out_row_offset = row_map
     d.split_k = split_k
     d.accumulate = int(accumulate)
+    if colsum_out is not None:  # column sums of C (a bias gradient): fused into the epilogue or a vit_colsum pass
+        _chk(colsum_out, torch.float32, "gemm colsum_out")
+        if colsum_out.numel() != N:
+            raise _cabi.VitError(f"gemm: colsum_out must have N={N} elements")
+        d.colsum_out = colsum_out.data_ptr()
+        h.ensure_workspace(max(2 * (-(-M // 256)), 2048) * N * 4)
     if split_k != 0 and split_k != 1:
         if split_k < 0:  # upper bound over the automatic choices of both GEMM cores (gemm.hip / gemm2.hip)
             tiles = -(-M // 128) * -(-N // 128)
