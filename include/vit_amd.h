@@ -48,6 +48,10 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                5 the 256x256xBK64 ping-pong variant (wave halves one barrier out of phase: LOAD segment beside MFMA
  *                segment, ring of 8 half-tiles, 4 in flight), 6 the 4-wave 256x128xBK32 (3 stages) geometry with two
  *                workgroups per CU.
+ *   "attn_split": workgroups per (batch, head) in the resident attention kernels (T <= 256), default 2.
+ *   "gemm_pp_slots": 8 (default) or 10 half-tile slots in the ping-pong core's LDS ring: 64 or 96 KiB of operand
+ *                loads in flight per CU (10 puts the epilogue scratch on ring slots that are free at a tile boundary;
+ *                measured 0-15 % slower on the ViT-B shapes: the loop is not bound by bytes in flight).
  *   "gemm_debug": timing diagnostics for the LDS-DMA core (1 = skip operand DMA after the prologue, 2 = skip MFMAs);
  *                results are meaningless while it is non-zero.
  *                Returns VIT_ERR_ARG for an unknown name. */

@@ -387,3 +387,43 @@ def test_rope_model_matches_oracle(dev, precision):
             assert cos > 0.999 and rel(mine, ref) < 8e-2, (name, cos, rel(mine, ref))
         checked += 1
     assert checked > 20
+
+
+@pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
+def test_padded_rows_do_not_leak(dev, precision):
+    """hidden % 256 == 0 with B*T NOT a multiple of 256: the engine pads the GEMM row count to the 256-row tiles of the
+    ping-pong core (zeroed pad rows); outputs, loss and every gradient must equal the oracle's on the real rows, twice in
+    a row (the pad rows of the re-used buffers must stay inert), and for two batch sizes."""
+    from oracle import refvit
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    rc = refvit.RefConfig(image_size=288, patch_size=32, hidden_size=256, num_hidden_layers=2, num_attention_heads=4,
+                          stride_size=32, loss_name="mae")
+    sd = refvit.make_state_dict(rc, 61)
+    cfg = ViTConfig(task_type="reg", image_size=288, patch_size=32, hidden_size=256, num_hidden_layers=2,
+                    num_attention_heads=4, stride_size=32)
+    model = MyViT(cfg, loss_name="mae")
+    model.set_precision(precision)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    tight = precision == "32"
+    for B, seed in ((5, 62), (27, 63), (5, 62)):
+        flux, _, labels = refvit.make_inputs(rc, B, seed)
+        tr = refvit.RefTrainer(rc, sd, training=False)
+        ref = refvit.forward(rc, tr.params, flux, labels)
+        ref.loss.backward()
+        model.zero_grad()
+        out = model(flux.to(dev), labels=labels.to(dev))
+        assert rel(out.logits, ref.logits.detach()) < (1e-4 if tight else 2e-2)
+        out.loss.backward()
+        for name, p in model.named_parameters():
+            g = tr.params[name].grad
+            if g is None or float(g.norm()) < 1e-6:
+                continue
+            mine = p.grad.reshape(g.shape).cpu()
+            if tight:
+                assert rel(mine, g) < 3e-4, (name, B)
+            else:
+                cos = float(torch.dot(mine.flatten().double(), g.flatten().double()) / (mine.double().norm() * g.double().norm()))
+                assert cos > 0.995, (name, B, cos)

@@ -20,7 +20,11 @@ def main():
     ap.add_argument("--cores", default="0,2,6")
     ap.add_argument("--M", type=int, default=50432)
     args = ap.parse_args()
-    cores = [int(c) for c in args.cores.split(",")]
+    cores = [c for c in args.cores.split(",")]  # "5" or "5s8" / "5s10": ping-pong core with an 8- / 10-slot ring
+    def select(c):
+        core, _, slots = c.partition("s")
+        _cabi.set_option("gemm_core", int(core))
+        _cabi.set_option("gemm_pp_slots", int(slots) if slots else 8)
     dev = torch.device("cuda:0")
     M, D, F = args.M, 768, 3072
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -54,7 +58,7 @@ def main():
     for r in range(args.rounds + 1):
         for name, (fn, fl) in cases.items():
             for c in cores:
-                _cabi.set_option("gemm_core", c)
+                select(c)
                 fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -65,6 +69,7 @@ def main():
                 if r:
                     times[name][c].append(e0.elapsed_time(e1) / 3)
     _cabi.set_option("gemm_core", 1)
+    _cabi.set_option("gemm_pp_slots", 8)
     tot = {c: 0.0 for c in cores}
     print(f"{'case':48s} " + " ".join(f"core{c}: us / TF".rjust(20) for c in cores))
     for name, (fn, fl) in cases.items():

@@ -13,7 +13,8 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode, g_gemm2_debug;  // gemm2.hip
+extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots;  // gemm2.hip
+extern int g_attn_split;                           // attention.hip
 
 static thread_local char g_err[512] = "";
 thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
@@ -71,6 +72,16 @@ int vit_set_option(const char* name, int value) {
   if (strcmp(name, "gemm_core") == 0) {
     VIT_CHECK(value >= 0 && value <= 6, VIT_ERR_ARG, "vit_set_option: gemm_core must be 0..6");
     vit::g_gemm2_mode = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "attn_split") == 0) {
+    if (value < 1 || value > 8) return VIT_ERR_ARG;
+    vit::g_attn_split = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "gemm_pp_slots") == 0) {
+    if (value != 8 && value != 10) return VIT_ERR_ARG;
+    vit::g_pp_slots = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_debug") == 0) {  // timing diagnostics of the LDS-DMA core; results are meaningless when set

@@ -33,6 +33,7 @@ struct AttnArgs {
   int B, H, T, dh;
   float scale;
   DropCfg drop;
+  int nsplit, wpw;  // resident kernels: workgroups per (batch, head) and waves per workgroup (row tiles are dealt in order)
 };
 
 template <int DH>
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
   const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   char* Vimg = smem + ntl * TILE;
   load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
   __syncthreads();
-  const int q00 = wave * RQ * 16;
+  const int q00 = (part * p.wpw + wave) * RQ * 16;
   if (q00 >= T) return;  // no barrier after this point
 
   bf16x8 qf[RQ][DH / 32];
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
   const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   char* Vimg = smem + ntl * TILE;
   load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
   __syncthreads();
-  const int q00 = wave * RQ * 16;
+  const int q00 = (part * p.wpw + wave) * RQ * 16;
   if (q00 >= T) return;
 
   bf16x8 qf[RQ][DH / 32], dof[RQ][DH / 32];
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+  const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
   const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
     del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
   }
   __syncthreads();
-  const int k00 = wave * RQ * 16;
+  const int k00 = (part * p.wpw + wave) * RQ * 16;
   if (k00 >= T) return;
 
   bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
 }
 
 constexpr int RES_MAX_T = 256, RES_MAX_DH = 64, RES_RQ = 2;
+int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
 
 template <typename F>
 static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
@@ -869,8 +871,15 @@ static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
     VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
+  // several workgroups per (batch, head), each staging the whole K / V (or Q / dO) but owning a share of the row tiles:
+  // with 4-wave workgroups three of them fit a CU (150 KiB of LDS, 12 of the 12 wave slots 152 VGPRs leave), so the
+  // staging latency of one hides behind the key loops of the others; one 7-wave workgroup per CU paid it in the open.
   const int nq = cdiv(a.T, 16), nw = cdiv(nq, RES_RQ);
-  hipLaunchKernelGGL(fn, dim3(a.B * a.H), dim3(nw * 64), smem, st, a);
+  AttnArgs b = a;
+  b.nsplit = std::max(1, std::min(g_attn_split, nw));
+  b.wpw = cdiv(nw, b.nsplit);
+  b.nsplit = cdiv(nw, b.wpw);
+  hipLaunchKernelGGL(fn, dim3(a.B * a.H * b.nsplit), dim3(b.wpw * 64), smem, st, b);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

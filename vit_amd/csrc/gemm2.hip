@@ -459,16 +459,23 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
 // stream runs through tile boundaries; at a boundary the groups re-align (one extra barrier each, on opposite sides of
 // the epilogue) so that all eight waves run their epilogues concurrently, and the first four phases after it count the
 // epilogue's >= 32 stores per wave into the vmcnt budget instead of draining them.
-template <int A_T, int B_T, int EPI>
+template <int A_T, int B_T, int EPI, int NSLOT>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * BK * 2;     // one half-tile image: 16 KiB
-  constexpr int RING = 8 * HALF;         // 2 K-tiles x 4 half-tiles
+  // NSLOT half-tile slots, stream index h lives in slot h % NSLOT and is issued in phase h - DEPTH, DEPTH = NSLOT - 3 (the
+  // first phase >= 2 after the last read of the slot it overwrites); each phase's wait leaves DEPTH - 1 half-tiles in flight.
+  // NSLOT = 8: 64 KiB in flight, separate 32 KiB epilogue scratch.  NSLOT = 10: the ring takes all 160 KiB, 96 KiB in
+  // flight (operands that miss L2 -- dW streams every byte from HBM / Infinity Cache -- are latency-bound: bytes in flight
+  // over latency), and the epilogue scratch aliases the two slots that are free at a tile boundary, B1 and A1 of the
+  // K-tile just finished (restaged in phases 1 and 2 of the next K-tile; waves 0-3 own the first, 4-7 the second, and a
+  // wave half restages only after its own epilogue, the other half's DMA into the same slot comes a barrier later).
+  constexpr int DEPTH = NSLOT - 3, INFL = 2 * (DEPTH - 1);
   constexpr int SCR = 4096, CW = 64;     // epilogue scratch per wave
   constexpr int XA0 = 0, XB0 = 1, XB1 = 2, XA1 = 3;
   // vmcnt budget of the four phases after an epilogue: the usual 8 + the FEWEST vector-memory operations that epilogue
   // issues per wave (its stores: 16 x 16 B for the bf16 kinds, 32 otherwise) -- a lower bound keeps the wait conservative
-  constexpr int RELAX = 8 + ((EPI >= 3 && EPI <= 6) ? 16 : 32);
+  constexpr int RELAX = INFL + ((EPI >= 3 && EPI <= 6) ? 16 : 32);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -545,8 +552,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     }
   };
   // one half-tile = 2 LDS-DMA instructions per thread; destination: slot + round*8 KiB + wave*1 KiB (+ lane*16)
-  auto issue_half = [&](const char* base, long half_off, const int (&off)[2], int it, int x) {
-    char* dst = smem + (((it & 1) << 2) + x) * HALF + wave * 1024;
+  int islot = 0;  // slot of the next stream index to issue (stream order: A0 B0 B1 A1 per K-tile)
+  auto issue_half = [&](const char* base, long half_off, const int (&off)[2]) {
+    char* dst = smem + islot * HALF + wave * 1024;
+    islot = (islot + 1 == NSLOT) ? 0 : islot + 1;
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
   };
@@ -597,29 +606,45 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   __builtin_amdgcn_s_barrier();
 // stage one half-tile of K-tile IT (if it exists) and leave four half-tiles in flight; `relaxed`: the epilogue's stores
 // were issued after the three older half-tiles still in flight -- count them in instead of draining them
-#define PP_STAGE(IT, BASE, HOFF, OFF, X)                                                         \
+#define PP_STAGE(IT, BASE, HOFF, OFF)                                                            \
   if ((IT) < T) {                                                                                \
-    issue_half(BASE, HOFF, OFF, IT, X);                                                          \
+    issue_half(BASE, HOFF, OFF);                                                                 \
     if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAX) : "memory");                    \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");                             \
   } else {                                                                                       \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
   }
+// phase x (0..3) of K-tile `it` issues stream index 4 it + 1 + x + DEPTH: half X = (1 + x + DEPTH) % 4 of K-tile
+// it + (1 + x + DEPTH) / 4 (DEPTH 5: B1, A1 of it+1, then A0, B0 of it+2; DEPTH 7: A0 B0 B1 A1 of it+2)
+#define PP_STAGE_X(XP)                                                                           \
+  {                                                                                              \
+    constexpr int hx_ = 1 + (XP) + DEPTH, ko_ = hx_ / 4, X_ = hx_ % 4;                           \
+    const char* ba_ = (ko_ == 1) ? a1 : a2;                                                      \
+    const char* bb_ = (ko_ == 1) ? bb1 : bb2;                                                    \
+    if (X_ == 0) { PP_STAGE(it + ko_, ba_, 0, offA) }                                            \
+    else if (X_ == 1) { PP_STAGE(it + ko_, bb_, 0, offB) }                                       \
+    else if (X_ == 2) { PP_STAGE(it + ko_, bb_, halfB, offB) }                                   \
+    else { PP_STAGE(it + ko_, ba_, halfA, offA) }                                                \
+  }
 
-  // ---- prologue: stream indices 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
+  // ---- prologue: stream indices 0..DEPTH (K-tile 0, and K-tile 1 up to B0 or whole)
   const char *a1 = nullptr, *bb1 = nullptr, *a2 = nullptr, *bb2 = nullptr;  // bases of K-tiles it+1, it+2
   {
     const char *a0, *bb0;
     cursor_next(a0, bb0);
-    issue_half(a0, 0, offA, 0, XA0);
-    issue_half(bb0, 0, offB, 0, XB0);
-    issue_half(bb0, halfB, offB, 0, XB1);
-    issue_half(a0, halfA, offA, 0, XA1);
+    issue_half(a0, 0, offA);
+    issue_half(bb0, 0, offB);
+    issue_half(bb0, halfB, offB);
+    issue_half(a0, halfA, offA);
     if (1 < T) {
       cursor_next(a1, bb1);
-      issue_half(a1, 0, offA, 1, XA0);
-      issue_half(bb1, 0, offB, 1, XB0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      issue_half(a1, 0, offA);
+      issue_half(bb1, 0, offB);
+      if (DEPTH == 7) {
+        issue_half(bb1, halfB, offB);
+        issue_half(a1, halfA, offA);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
@@ -628,26 +653,30 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
-  char* scr = smem + RING + wave * SCR;
+  int rslot = 0;  // slot of A0 of the current K-tile (stream index 4 it)
+  auto slot_ptr = [&](int x) -> char* {
+    int sl = rslot + x;
+    if (sl >= NSLOT) sl -= NSLOT;
+    return smem + sl * HALF;
+  };
   int kt = 0, jt = 0;
   bool relaxed = false;
   for (int it = 0; it < T; ++it) {
-    const char* ring = smem + ((it & 1) << 2) * HALF;
     // P1
-    PP_READ_B(b0, ring + XB0 * HALF)
-    PP_READ_A(ring + XA0 * HALF)
-    PP_STAGE(it + 1, bb1, halfB, offB, XB1)
+    PP_READ_B(b0, slot_ptr(XB0))
+    PP_READ_A(slot_ptr(XA0))
+    PP_STAGE_X(0)
     PP_MFMA(0, 0, b0)
     // P2
-    PP_READ_B(b1, ring + XB1 * HALF)
-    PP_STAGE(it + 1, a1, halfA, offA, XA1)
+    PP_READ_B(b1, slot_ptr(XB1))
+    PP_STAGE_X(1)
     PP_MFMA(0, 1, b1)
     // P3
-    PP_READ_A(ring + XA1 * HALF)
-    PP_STAGE(it + 2, a2, 0, offA, XA0)
+    PP_READ_A(slot_ptr(XA1))
+    PP_STAGE_X(2)
     PP_MFMA(1, 1, b1)
     // P4
-    PP_STAGE(it + 2, bb2, 0, offB, XB0)
+    PP_STAGE_X(3)
     PP_MFMA(1, 0, b0)
     relaxed = false;
     a1 = a2; bb1 = bb2;
@@ -658,24 +687,29 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
       tile_coords(jt, tm, tn);
       ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
+      char* scr = (NSLOT == 8) ? smem + 8 * HALF + wave * SCR : slot_ptr(wave < 4 ? XB1 : XA1) + (wave & 3) * SCR;
       if constexpr (EPI >= 3) pp_epilogue<EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       else tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
       relaxed = true;
     }
+    rslot += 4;
+    if (rslot >= NSLOT) rslot -= NSLOT;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier of the other group
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_MFMA
 #undef PP_STAGE
+#undef PP_STAGE_X
 }
 
-template <int AT, int BT, int EPI>
-static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
+int g_pp_slots = 8;  // vit_set_option("gemm_pp_slots"): half-tile slots of the ping-pong ring, 8 (default) or 10
+template <int AT, int BT, int EPI, int NSLOT>
+static int launch_stag_n(const Gemm2Args& a, dim3 grid, hipStream_t st) {
   constexpr int smem = 160 * 1024;
   static bool attr_done = false;
-  auto fn = gemm3_kernel<AT, BT, EPI>;
+  auto fn = gemm3_kernel<AT, BT, EPI, NSLOT>;
   if (!attr_done) {
     VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
@@ -683,6 +717,10 @@ static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL(fn, grid, dim3(512), smem, st, a);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
+}
+template <int AT, int BT, int EPI>
+static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
+  return g_pp_slots == 8 ? launch_stag_n<AT, BT, EPI, 8>(a, grid, st) : launch_stag_n<AT, BT, EPI, 10>(a, grid, st);
 }
 static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
   if (epi == 1) return launch_stag<0, 0, 1>(a, grid, st);

@@ -251,29 +251,39 @@ class ViTEngine:
         T, D, Fd, H, L, N, P = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
             c.num_hidden_layers, c.num_patches, c.patch_size
         M = B * T
+        # GEMM row count: token rows padded to the 256-row tiles of the ping-pong GEMM core when the widths allow it.
+        # Every buffer a GEMM reads or writes is allocated ZEROED with Mp rows and used through its first M rows by
+        # everything else (LayerNorm, attention, reducers write real rows only), so pad rows hold zeros or finite
+        # bias-only values in the forward tensors and exact zeros in every gradient tensor: dW = dY^T X over Mp rows
+        # equals the sum over the M real rows, and bias-gradient column sums likewise.
+        Mp = -(-M // 256) * 256 if (D % 256 == 0 and Fd % 256 == 0) else M
+        self._Mp = Mp
         nl = L if train else 1
         f32, b16 = torch.float32, self.adt  # "b16" = the activation/operand dtype of the current precision mode
 
         def E(shape, dt):
             return torch.empty(shape, dtype=dt, device=dev)
 
+        def G(cols, dt):  # a GEMM operand / result with M real rows (+ zeroed pad rows behind the view)
+            return torch.zeros((Mp, cols), dtype=dt, device=dev)[:M]
+
         self.act = dict(
             patches=E((B * N, P), b16),
             x=[E((B, T, D), f32) for _ in range(L + 1)],
-            h1=[E((M, D), b16) for _ in range(nl)], qkv=[E((M, 3 * D), b16) for _ in range(nl)],
-            ctx=[E((M, D), b16) for _ in range(nl)], lse=[E((B * H, T), f32) for _ in range(nl)],
-            x1=[E((M, D), f32) for _ in range(nl)], h2=[E((M, D), b16) for _ in range(nl)],
-            u=[E((M, Fd), b16) for _ in range(nl)], g=[E((M, Fd), b16) for _ in range(nl)],
+            h1=[G(D, b16) for _ in range(nl)], qkv=[G(3 * D, b16) for _ in range(nl)],
+            ctx=[G(D, b16) for _ in range(nl)], lse=[E((B * H, T), f32) for _ in range(nl)],
+            x1=[E((M, D), f32) for _ in range(nl)], h2=[G(D, b16) for _ in range(nl)],
+            u=[G(Fd, b16) for _ in range(nl)], g=[G(Fd, b16) for _ in range(nl)],
             mean1=[E((M,), f32) for _ in range(nl)], rstd1=[E((M,), f32) for _ in range(nl)],
             mean2=[E((M,), f32) for _ in range(nl)], rstd2=[E((M,), f32) for _ in range(nl)],
             last=E((B, T, D), f32), meanF=E((M,), f32), rstdF=E((M,), f32),
-            y=E((M, D), b16),  # dropout(Linear(.)) of the attention-output / FC2 projection, until the next LayerNorm adds it
+            y=G(D, b16),  # dropout(Linear(.)) of the attention-output / FC2 projection, until the next LayerNorm adds it
         )
         self.tmp = {}
         if train:
             self.tmp = dict(
-                dxa=E((M, D), f32), dxb=E((M, D), f32), dy=E((M, D), b16), dU=E((M, Fd), b16), dh=E((M, D), b16),
-                dqkv=E((M, 3 * D), b16), dctx=E((M, D), b16), delta=E((B * H, T), f32), dpatch=E((B * N, D), b16),
+                dxa=E((M, D), f32), dxb=E((M, D), f32), dy=G(D, b16), dU=G(Fd, b16), dh=G(D, b16),
+                dqkv=G(3 * D, b16), dctx=G(D, b16), delta=E((B * H, T), f32), dpatch=E((B * N, D), b16),
                 dlast=E((B, T, D), f32),
             )
         self._arena_key = key
@@ -309,6 +319,7 @@ class ViTEngine:
             c.num_hidden_layers, c.num_patches, c.patch_size, c.stride
         dh, M = c.head_dim, B * T
         self._ensure_arena(B, need_grad)
+        Mp = self._Mp
         a = self.act
         ph = c.hidden_dropout_prob if training else 0.0
         pa = c.attention_probs_dropout_prob if training else 0.0
@@ -342,19 +353,19 @@ class ViTEngine:
                 self._ln(xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
             else:
                 self._ln_res(a["x1"][jprev], y, xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
-            vf.gemm(a["h1"][j], self._qkv16(i), M=M, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
+            vf.gemm(a["h1"][j], self._qkv16(i), M=Mp, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
             if rope is not None:  # vit_with_rope.py:58-60: q, k rotated per head before the scores
                 vf.rope_qk(a["qkv"][j], rope[0], rope[1], T, H, dh)
             vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
                              lse=a["lse"][j])
             if output_attentions:
                 atts.append(vf.attention_probs(a["qkv"][j], B, H, T, dh, scale))
-            vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, out=y,
+            vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, out=y,
                     bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)))
             self._ln_res(xin, y, a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
-            vf.gemm(a["h2"][j], self.w16(pre + "intermediate.dense.weight"), M=M, N=Fd, K=D, out=a["g"][j],
+            vf.gemm(a["h2"][j], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=Fd, K=D, out=a["g"][j],
                     bias=self.p(pre + "intermediate.dense.bias"), act=ACT_GELU, aux_out=a["u"][j] if need_grad else None)
-            vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=M, N=D, K=Fd, out=y,
+            vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=Mp, N=D, K=Fd, out=y,
                     bias=self.p(pre + "output.dense.bias"), dropout=(ph, seed, self._site(i, 2)))
             jprev = j
         if L > 0:
@@ -395,6 +406,7 @@ class ViTEngine:
         T, D, Fd, H, L, N, P = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
             c.num_hidden_layers, c.num_patches, c.patch_size
         dh, M = c.head_dim, B * T
+        Mp = self._Mp
         scale = dh ** -0.5
         rope = self._rope_tables(T) if c.pos_encoding_type == "rope" else None
         cb = self.grad_ready_cb
@@ -415,30 +427,30 @@ class ViTEngine:
         for i in reversed(range(L)):
             pre = f"vit.encoder.layer.{i}."
             # x2 = dropout(g W2^T + b2) + x1      (t["dy"] = mask * dx and db2 were produced by the LN backward above)
-            vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=M, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
+            vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=Mp, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
                     split_k=-1)
-            vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=M, N=Fd, K=D, b_trans=True, out=t["dU"],
+            vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=Mp, N=Fd, K=D, b_trans=True, out=t["dU"],
                     act=vf.ACT_DGELU, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
-            vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=M, a_trans=True, b_trans=True,
+            vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=Mp, a_trans=True, b_trans=True,
                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
-            vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=M, N=D, K=Fd, b_trans=True, out=t["dh"])
+            vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=D, K=Fd, b_trans=True, out=t["dh"])
             # x1 = dropout(ctx Wo^T + bo) + x:  LN2 backward -> dx1, and dya = mask * dx1 with dbo
             vf.layernorm_bwd_fused(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i],
                                    a["rstd2"][i], dx, dx_other, self.g(pre + "layernorm_after.weight"),
                                    self.g(pre + "layernorm_after.bias"), t["dy"],
                                    self.g(pre + "attention.output.dense.bias"), (ph, seed, self._site(i, 1)))
             dx, dx_other = dx_other, dx
-            vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=M, a_trans=True, b_trans=True,
+            vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
-            vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=M, N=D, K=D, b_trans=True, out=t["dctx"])
+            vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, b_trans=True, out=t["dctx"])
             vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
                              dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"])
             if rope is not None:  # gradient wrt the un-rotated q, k: the inverse rotation
                 vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
             vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
-            vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=M, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
+            vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
                     split_k=-1)
-            vf.gemm(t["dqkv"], self._qkv16(i), M=M, N=D, K=3 * D, b_trans=True, out=t["dh"])
+            vf.gemm(t["dqkv"], self._qkv16(i), M=Mp, N=D, K=3 * D, b_trans=True, out=t["dh"])
             if i > 0:
                 # LN1 backward -> dx (input of this layer = output of layer i-1), plus layer i-1's FC2 pieces
                 prev = f"vit.encoder.layer.{i - 1}."
