@@ -32,7 +32,10 @@ typedef void* vit_stream; /* hipStream_t */
 
 typedef enum { VIT_OK = 0, VIT_ERR_ARG = -1, VIT_ERR_HIP = -2, VIT_ERR_UNSUPPORTED = -3, VIT_ERR_WORKSPACE = -4 } vit_status;
 typedef enum { VIT_F32 = 0, VIT_BF16 = 1 } vit_dtype;
-typedef enum { VIT_ACT_NONE = 0, VIT_ACT_GELU = 1, VIT_ACT_DGELU = 2 } vit_act;
+/* GELU: C = gelu(acc + bias), aux_out (optional) = the pre-activation.  DGELU: C = acc * gelu'(aux_in).
+ * GELU_GRAD: as GELU but aux_out = gelu'(pre-activation) -- the forward already holds Phi and exp(-x^2/2), so saving the
+ * derivative costs two FMAs there and the backward GEMM (MUL_AUX: C = acc * aux_in) needs no transcendental at all. */
+typedef enum { VIT_ACT_NONE = 0, VIT_ACT_GELU = 1, VIT_ACT_DGELU = 2, VIT_ACT_GELU_GRAD = 3, VIT_ACT_MUL_AUX = 4 } vit_act;
 typedef enum { VIT_LOSS_MSE = 0, VIT_LOSS_L1 = 1, VIT_LOSS_CE = 2 } vit_loss;
 
 int vit_version(void);

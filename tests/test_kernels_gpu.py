@@ -591,3 +591,31 @@ def test_gemm_colsum_out(dev, core):
         assert torch.equal(again, cs2)  # deterministic
     finally:
         _cabi.set_option("gemm_core", 1)
+
+
+@pytest.mark.parametrize("core", [0, 1, 2])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_gemm_gelu_grad_and_mul_aux(dev, core, dt):
+    """ACT_GELU_GRAD saves gelu'(pre-activation) in the forward, ACT_MUL_AUX multiplies by it in the backward: together they
+    must reproduce autograd through F.gelu (every core; f32 operands run the split-bf16 kernel)."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+    from vit_amd._cabi import ACT_GELU_GRAD, ACT_MUL_AUX
+
+    M, N, K = 512, 768, 256
+    cast = (lambda t: bf(t)) if dt == torch.bfloat16 else (lambda t: t)
+    x, W, bias = cast(randn((M, K), dev, 120)), cast(randn((N, K), dev, 121, 0.1)), randn((N,), dev, 122)
+    dy, W2 = cast(randn((M, K), dev, 123)), cast(randn((K, N), dev, 124, 0.1))
+    _cabi.set_option("gemm_core", core)
+    try:
+        aux = torch.empty((M, N), dtype=dt, device=dev)
+        y = vf.gemm(x, W, M=M, N=N, K=K, bias=bias, act=ACT_GELU_GRAD, aux_out=aux, out_dtype=dt)
+        dU = vf.gemm(dy, W2, M=M, N=N, K=K, b_trans=True, act=ACT_MUL_AUX, aux_in=aux, out_dtype=dt)
+    finally:
+        _cabi.set_option("gemm_core", 1)
+    pre = (x.float() @ W.float().t() + bias).requires_grad_(True)
+    ref = F.gelu(pre)
+    ref.backward(dy.float() @ W2.float())
+    tol = 6e-3 if dt == torch.bfloat16 else 2e-5
+    assert rel(y, ref.detach()) < tol
+    assert rel(dU, pre.grad) < (8e-3 if dt == torch.bfloat16 else 3e-5)

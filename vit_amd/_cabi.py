@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vit_amd.h")
 
 VIT_OK = 0
 VIT_F32, VIT_BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
 LOSS_MSE, LOSS_L1, LOSS_CE = 0, 1, 2
 
 

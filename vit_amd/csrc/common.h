@@ -113,6 +113,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   phi_parts(x, cdf, ex);
   return x * cdf;
 }
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {  // gelu(x) and gelu'(x) from one phi_parts
+  float cdf, ex;
+  phi_parts(x, cdf, ex);
+  g = x * cdf;
+  dg = fmaf(x * 0.39894228040143267794f, ex, cdf);
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
   float cdf, ex;
   phi_parts(x, cdf, ex);

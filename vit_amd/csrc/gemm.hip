@@ -83,27 +83,41 @@ __device__ __forceinline__ void generic_epilogue(f32x4 (&acc)[4][4], const GemmA
       if (n >= p.N) continue;
       f32x4 v = acc[i][j] * p.alpha;
       if (p.bias) v += *(const f32x4*)(p.bias + n);
-      if (p.act == VIT_ACT_GELU) {
+      if (p.act == VIT_ACT_GELU || p.act == VIT_ACT_GELU_GRAD) {
+        f32x4 sv = v;  // what aux_out receives: the pre-activation, or gelu'(pre-activation)
+        if (p.act == VIT_ACT_GELU_GRAD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float g_, d_;
+            gelu_both(v[r], g_, d_);
+            v[r] = g_;
+            sv[r] = d_;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
         if (p.aux_out) {
           if (AUX_F32) {
-            *(f32x4*)((float*)p.aux_out + orow * p.ldaux + n) = v;
+            *(f32x4*)((float*)p.aux_out + orow * p.ldaux + n) = sv;
           } else {
-            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            u32x2 pk = {pack2bf(sv[0], sv[1]), pack2bf(sv[2], sv[3])};
             *(u32x2*)(p.aux_out + orow * p.ldaux + n) = pk;
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      } else if (p.act == VIT_ACT_DGELU) {
+      } else if (p.act == VIT_ACT_DGELU || p.act == VIT_ACT_MUL_AUX) {
+        f32x4 u;
         if (AUX_F32) {
-          const f32x4 u = *(const f32x4*)((const float*)p.aux_in + orow * p.ldaux + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(u[r]);
+          u = *(const f32x4*)((const float*)p.aux_in + orow * p.ldaux + n);
         } else {
-          bf16x4 u = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
+          const bf16x4 ub = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
+          u = (f32x4){bf2f(ub[0]), bf2f(ub[1]), bf2f(ub[2]), bf2f(ub[3])};
         }
+        if (p.act == VIT_ACT_DGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = dgelu_erf(u[r]);
+        }
+        v *= u;
       }
       if (p.drop.thr) {
         float k0, k1, k2, k3;
@@ -492,7 +506,10 @@ static int gemm_launch_core(vit_handle h, const vit_gemm_desc* d, hipStream_t st
             VIT_ERR_ARG, "vit_gemm: leading dimension smaller than the row length");
   if (d->bias) VIT_CHECK(al16(d->bias), VIT_ERR_ARG, "vit_gemm: bias must be 16-byte aligned");
   if (d->residual) VIT_CHECK(al16(d->residual) && (d->ldres % 4) == 0, VIT_ERR_ARG, "vit_gemm: residual alignment");
-  if (d->act == VIT_ACT_DGELU) VIT_CHECK(d->aux_in && (d->ldaux % 4) == 0, VIT_ERR_ARG, "vit_gemm: ACT_DGELU needs aux_in");
+  VIT_CHECK(d->act >= VIT_ACT_NONE && d->act <= VIT_ACT_MUL_AUX, VIT_ERR_ARG, "vit_gemm: bad act %d", d->act);
+  if (d->act == VIT_ACT_DGELU || d->act == VIT_ACT_MUL_AUX)
+    VIT_CHECK(d->aux_in && (d->ldaux % 4) == 0, VIT_ERR_ARG, "vit_gemm: ACT_DGELU / ACT_MUL_AUX need aux_in");
+  if (d->act == VIT_ACT_GELU_GRAD) VIT_CHECK(d->aux_out, VIT_ERR_ARG, "vit_gemm: ACT_GELU_GRAD needs aux_out");
   if (d->aux_out) VIT_CHECK((d->ldaux % 4) == 0 && d->ldaux >= d->N, VIT_ERR_ARG, "vit_gemm: bad ldaux");
   VIT_CHECK(d->dropout_p >= 0.f && d->dropout_p < 1.f, VIT_ERR_ARG, "vit_gemm: dropout_p out of [0,1)");
 

@@ -112,16 +112,32 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[WM][WN], char* scr, c
         v *= p.alpha;
         if (p.bias) v += *(const f32x4*)(p.bias + n);
         if (EPI == 1) {
+          f32x4 sv = v;  // aux_out: the pre-activation (ACT_GELU) or gelu' of it (ACT_GELU_GRAD)
+          if (p.act == VIT_ACT_GELU_GRAD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float g_, d_;
+              gelu_both(v[r], g_, d_);
+              v[r] = g_;
+              sv[r] = d_;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+          }
           if (p.aux_out) {
-            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            u32x2 pk = {pack2bf(sv[0], sv[1]), pack2bf(sv[2], sv[3])};
             *(u32x2*)(p.aux_out + orow * p.ldaux + n) = pk;
           }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         } else if (EPI == 2) {
           bf16x4 u = *(const bf16x4*)(p.aux_in + orow * p.ldaux + n);
+          if (p.act == VIT_ACT_MUL_AUX) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
+            for (int r = 0; r < 4; ++r) v[r] *= bf2f(u[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= dgelu_erf(bf2f(u[r]));
+          }
         }
         if (p.drop.thr) {
           float k0, k1, k2, k3;
@@ -384,19 +400,41 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
         o[4 + r] = v[rr][1][r] + bv1[r];
       }
       if (FAST == 4) {
+        float sv[8];  // aux_out: the pre-activation (ACT_GELU) or gelu' of it (ACT_GELU_GRAD: two FMAs on top of the GELU)
+        if (p.act == VIT_ACT_GELU_GRAD) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            float g_, d_;
+            gelu_both(o[r], g_, d_);
+            o[r] = g_;
+            sv[r] = d_;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            sv[r] = o[r];
+            o[r] = gelu_erf(o[r]);
+          }
+        }
         if (p.aux_out) {
-          u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+          u32x4 pk = {pack2bf(sv[0], sv[1]), pack2bf(sv[2], sv[3]), pack2bf(sv[4], sv[5]), pack2bf(sv[6], sv[7])};
           *(u32x4*)(p.aux_out + m * p.ldaux + n) = pk;
         }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = gelu_erf(o[r]);
       }
       if (FAST == 5) {
         const u32x4 u = au[i & 3][rr];
+        if (p.act == VIT_ACT_MUL_AUX) {  // aux_in already holds gelu'(.)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[2 * r] *= dgelu_erf(__builtin_bit_cast(float, u[r] << 16));
-          o[2 * r + 1] *= dgelu_erf(__builtin_bit_cast(float, u[r] & 0xFFFF0000u));
+          for (int r = 0; r < 4; ++r) {
+            o[2 * r] *= __builtin_bit_cast(float, u[r] << 16);
+            o[2 * r + 1] *= __builtin_bit_cast(float, u[r] & 0xFFFF0000u);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[2 * r] *= dgelu_erf(__builtin_bit_cast(float, u[r] << 16));
+            o[2 * r + 1] *= dgelu_erf(__builtin_bit_cast(float, u[r] & 0xFFFF0000u));
+          }
         }
       }
       if (FAST == 3 && p.drop.thr) {
@@ -754,10 +792,10 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   if (d->M % 256 || d->N % 128 || d->K % 64) return 0;
   if (d->lda * 256 >= (1L << 30) || d->ldb * 256 >= (1L << 30)) return 0;  // int offsets inside a tile
   int epi = 0;
-  if (d->act == VIT_ACT_GELU) {
+  if (d->act == VIT_ACT_GELU || d->act == VIT_ACT_GELU_GRAD) {
     if (d->a_trans || d->b_trans) return 0;
     epi = 1;
-  } else if (d->act == VIT_ACT_DGELU) {
+  } else if (d->act == VIT_ACT_DGELU || d->act == VIT_ACT_MUL_AUX) {
     if (d->a_trans || !d->b_trans) return 0;
     epi = 2;
   }

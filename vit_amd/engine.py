@@ -364,7 +364,8 @@ class ViTEngine:
                     bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)))
             self._ln_res(xin, y, a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
             vf.gemm(a["h2"][j], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=Fd, K=D, out=a["g"][j],
-                    bias=self.p(pre + "intermediate.dense.bias"), act=ACT_GELU, aux_out=a["u"][j] if need_grad else None)
+                    bias=self.p(pre + "intermediate.dense.bias"), act=vf.ACT_GELU_GRAD if need_grad else ACT_GELU,
+                    aux_out=a["u"][j] if need_grad else None)  # a["u"] holds gelu'(pre-activation) for the backward
             vf.gemm(a["g"][j], self.w16(pre + "output.dense.weight"), M=Mp, N=D, K=Fd, out=y,
                     bias=self.p(pre + "output.dense.bias"), dropout=(ph, seed, self._site(i, 2)))
             jprev = j
@@ -430,7 +431,7 @@ class ViTEngine:
             vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=Mp, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
                     split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=Mp, N=Fd, K=D, b_trans=True, out=t["dU"],
-                    act=vf.ACT_DGELU, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
+                    act=vf.ACT_MUL_AUX, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
             vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=Mp, a_trans=True, b_trans=True,
                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
             vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=D, K=Fd, b_trans=True, out=t["dh"])

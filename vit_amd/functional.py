@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _cabi
-from ._cabi import ACT_DGELU, ACT_GELU, ACT_NONE, LOSS_CE, LOSS_L1, LOSS_MSE, VIT_BF16, VIT_F32, GemmDesc, check
+from ._cabi import ACT_DGELU, ACT_GELU, ACT_GELU_GRAD, ACT_MUL_AUX, ACT_NONE, LOSS_CE, LOSS_L1, LOSS_MSE, VIT_BF16, VIT_F32, GemmDesc, check
 
 _DT = {torch.float32: VIT_F32, torch.bfloat16: VIT_BF16}
 
