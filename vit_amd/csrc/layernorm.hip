@@ -219,7 +219,9 @@ static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float
                          const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
                          float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, DropCfg drop,
                          hipStream_t st) {
-  const int blocks = std::min(cdiv(rows, 16), 512);
+  // 4 blocks of 4 waves per CU: the block-combine LDS (4 waves x 3 x D floats = 36 KiB at D = 768) allows four, and with
+  // only two waves per SIMD (512 blocks) the pass was latency-bound at 4.3 TB/s (bytes in flight / HBM latency)
+  const int blocks = std::min(cdiv(rows, 16), 1024);
   const int np = dyn ? 3 : 2;
   size_t wsb = 0;
   float* part = (float*)ctx_workspace(h, &wsb);
