@@ -165,6 +165,11 @@ int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtyp
  * x.unfold(1,P,S) (+ zero pad of the ragged tail patch) -> patches [B*N, P] (bf16 or f32)   (tokenization.py:45-49) */
 int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, int B, int L, int P, int S, int N,
                     vit_stream stream);
+/* Backward of vit_unfold_cast wrt the signal, for a trainable input preprocessor (src/models/preprocessor.py:96-111 in
+ * front of src/models/tokenization.py:43-69): dx[B, L] (f32) = overlap-add of dpatches[B*N, P] (f32) over the windows that
+ * lie inside the signal.  Gather form, no atomics. */
+int vit_fold_add(vit_handle h, const float* dpatches, float* dx, int B, int L, int P, int S, int N, vit_stream stream);
+
 /* Training-time noise injection of ViTLModule.training_step (src/vit.py:86-88): out = flux + randn_like(flux) * error *
  * noise_level over n f32 elements (n % 4 == 0; out may alias flux).  The normal variates come from a counter-based
  * generator keyed on (seed, element index); the reference's come from torch's generator, whose stream is
@@ -216,6 +221,9 @@ int vit_head_loss_bwd(vit_handle h, const float* last_hidden, const float* W, co
  * Global L2 norm (squared) of a flat f32 gradient buffer -> out[0] (Lightning gradient_clip_val=0.5, norm clipping:
  * basemodule.py:244). Deterministic two-stage reduction. */
 int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream);
+/* out[0] += the squared norm of g: parameters that live outside the model's flat buffer (a trainable input
+ * preprocessor) join the same global clipping norm. */
+int vit_grad_sqnorm_acc(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream);
 /* torch.optim.AdamW step (opt/optimizer.py:16,108: lr, weight_decay=0 by default) over a flat parameter buffer, with
  * the clip coefficient min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) applied to g on the fly (sqnorm may be NULL).
  * Also refreshes the bf16 shadow copy used by the GEMMs (p_bf16 may be NULL). bias_correction uses `step` (1-based). */

@@ -21,9 +21,14 @@ def t(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+for dp in ((0.1, 1, 2), (0.0, 0, 0)):
+    _cabi.set_option("attn_split", 2)
+    f = t(lambda: vf.attention_fwd(qkv, B, H, T, dh, dh ** -0.5, dropout=dp, ctx=ctx, lse=lse))
+    b = t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=dp, dqkv=dqkv, delta=delta))
+    print(f"dropout p={dp[0]}: fwd {f:6.1f} us  bwd {b:6.1f} us", flush=True)
 ref = None
-for rnd in range(2):
-    for split in (1, 2, 3, 4):
+for rnd in range(1):
+    for split in (1, 2):
         _cabi.set_option("attn_split", split)
         f = t(lambda: vf.attention_fwd(qkv, B, H, T, dh, dh ** -0.5, dropout=drop, ctx=ctx, lse=lse))
         b = t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=drop, dqkv=dqkv, delta=delta))

@@ -67,6 +67,7 @@ _PROTOS = {
     "vit_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
     "vit_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vit_unfold_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vit_fold_add": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vit_add_noise": [_P, _P, _P, _P, C.c_long, _F, _U64, _P],
     "vit_rope_qk": [_P, _P, _I, _P, _P, C.c_long, _I, _I, _I, C.c_long, _I, _P],
     "vit_embed_finish": [_P, _P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],
@@ -77,6 +78,7 @@ _PROTOS = {
     "vit_head_loss_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vit_head_loss_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vit_grad_sqnorm": [_P, _P, _I64, _P, _P],
+    "vit_grad_sqnorm_acc": [_P, _P, _I64, _P, _P],
     "vit_adamw_step": [_P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I, _P, _F, _P],
 }
 _RESTYPES = {"vit_last_error": C.c_char_p, "vit_last_gemm_kernel": C.c_char_p}

@@ -65,16 +65,19 @@ __global__ void embed_finish_kernel(float* __restrict__ tok, const float* __rest
 // patch projection output (rows t >= 1) and the batch-summed gradients of cls_token (t == 0) / position_embeddings.
 template <int OUT_BF16>
 __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, void* __restrict__ dpatch,
-                                        float* __restrict__ dcls, float* __restrict__ dpos, int B, int T, int D,
-                                        DropCfg drop, int accumulate) {
+                                        float* __restrict__ part, int B, int T, int D, DropCfg drop, int bchunk) {
+  // blockIdx.y walks a chunk of the batch; its (t, 4 columns) sums go to part[blockIdx.y][T*D] (reduced afterwards in a
+  // fixed order: deterministic) -- one thread per (t, 4 columns) walking the WHOLE batch left 40 % of the CUs idle and
+  // serialised 256 loads per thread (205 us at B = 256)
   const int dv = D >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= T * dv) return;
   const int d = (i % dv) << 2;
   const int t = i / dv;
   const int N = T - 1;
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const long row = (long)b * T + t;
     f32x4 v = *(const f32x4*)(dtok + row * D + d);
     if (drop.thr) {
@@ -93,16 +96,7 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, void* __
       }
     }
   }
-  if (t == 0) {
-    f32x4 o = acc;
-    if (accumulate) o += *(const f32x4*)(dcls + d);
-    *(f32x4*)(dcls + d) = o;
-  }
-  if (dpos) {
-    f32x4 o = acc;
-    if (accumulate) o += *(const f32x4*)(dpos + (long)t * D + d);
-    *(f32x4*)(dpos + (long)t * D + d) = o;
-  }
+  *(f32x4*)(part + ((long)blockIdx.y * T + t) * D + d) = acc;
 }
 
 // ------------------------------------------------------------------------------------------ dropout bwd + cast
@@ -316,7 +310,8 @@ __global__ __launch_bounds__(256) void sqnorm_stage1_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(256) void sqnorm_stage2_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sqnorm_stage2_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out,
+                                                            int accumulate) {
   __shared__ float red[256];
   float a = 0.f;
   for (int i = threadIdx.x; i < nblk; i += 256) a += part[i];
@@ -326,7 +321,7 @@ __global__ __launch_bounds__(256) void sqnorm_stage2_kernel(const float* __restr
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + red[0] : red[0];
 }
 
 // torch.optim.AdamW (single-tensor form): p *= 1 - lr*wd; m,v EMA; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -364,6 +359,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float pp = p[i] * decay - step * mm / (sqrtf(vv) * rsqrt_bc2 + eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
     if (pb) pb[i] = f2bf(pp);
+  }
+}
+
+// ---- backward of the tokenizer's unfold (tokenization.py:43-49 / the Conv1d windows of :66-69) for a TRAINABLE input
+// preprocessor: dx[b, l] = sum over the windows n that cover l (n*S <= l < n*S + P, and the window lies entirely inside
+// the signal -- the others were zero patches, not taken from x) of dpatches[b, n, l - n*S].  Gather form: deterministic.
+__global__ __launch_bounds__(256) void fold_add_kernel(const float* __restrict__ dp, float* __restrict__ dx, int B, int L,
+                                                       int P, int S, int N) {
+  const long total = (long)B * L;
+  const int nvalid = min(N, (L - P) / S + 1);  // windows that fit
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / L), l = (int)(i - (long)b * L);
+    const int n_hi = min(nvalid - 1, l / S);
+    const int n_lo = max(0, (l - P + S) / S);  // ceil((l - P + 1) / S) for l - P + 1 > 0
+    float acc = 0.f;
+    for (int n = n_lo; n <= n_hi; ++n) acc += dp[((long)b * N + n) * P + (l - n * S)];
+    dx[i] = acc;
   }
 }
 
@@ -456,6 +468,17 @@ int vit_unfold_cast(vit_handle h, const float* x, void* patches, int out_dtype, 
   return VIT_OK;
 }
 
+int vit_fold_add(vit_handle h, const float* dpatches, float* dx, int B, int L, int P, int S, int N, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(dpatches && dx, VIT_ERR_ARG, "vit_fold_add: null pointer");
+  VIT_CHECK(B > 0 && L > 0 && P > 0 && S > 0 && N > 0 && P <= L, VIT_ERR_ARG, "vit_fold_add: B=%d L=%d P=%d S=%d N=%d", B, L,
+            P, S, N);
+  hipLaunchKernelGGL(fold_add_kernel, dim3(grid_for((long)B * L)), dim3(256), 0, (hipStream_t)stream, dpatches, dx, B, L, P,
+                     S, N);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
 int vit_add_noise(vit_handle h, const float* flux, const float* error, float* out, long n, float noise_level,
                   uint64_t seed, vit_stream stream) {
   (void)h;
@@ -503,17 +526,26 @@ int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float*
 int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, int dpatch_dtype, float* dcls, float* dpos,
                          int B, int T, int D, float dropout_p, uint64_t seed, uint64_t site, int accumulate,
                          vit_stream stream) {
-  (void)h;
   VIT_CHECK(dtokens && dpatch_out && dcls, VIT_ERR_ARG, "vit_embed_finish_bwd: null pointer");
   VIT_CHECK(B > 0 && T > 1 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_embed_finish_bwd: B=%d T=%d D=%d", B, T, D);
+  const int nchunk = std::min(B, 16), bchunk = cdiv(B, nchunk), ny = cdiv(B, bchunk);
+  size_t wsb = 0;
+  float* part = (float*)ctx_workspace(h, &wsb);
+  const size_t need = (size_t)ny * T * D * sizeof(float);
+  VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_embed_finish_bwd: needs %zu workspace bytes, have %zu", need, wsb);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(cdiv((long)T * (D / 4), 256), ny);
   if (dpatch_dtype == VIT_BF16)
-    hipLaunchKernelGGL(embed_finish_bwd_kernel<1>, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       dtokens, dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
+    hipLaunchKernelGGL(embed_finish_bwd_kernel<1>, grid, dim3(256), 0, st, dtokens, dpatch_out, part, B, T, D,
+                       make_drop(dropout_p, seed, site), bchunk);
   else
-    hipLaunchKernelGGL(embed_finish_bwd_kernel<0>, dim3(cdiv((long)T * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       dtokens, dpatch_out, dcls, dpos, B, T, D, make_drop(dropout_p, seed, site), accumulate);
+    hipLaunchKernelGGL(embed_finish_bwd_kernel<0>, grid, dim3(256), 0, st, dtokens, dpatch_out, part, B, T, D,
+                       make_drop(dropout_p, seed, site), bchunk);
   VIT_LAUNCH_CHECK();
-  return VIT_OK;
+  // dcls = sum over the batch of row t = 0; dpos (if any) = the sums of every row
+  int rc = launch_reduce_partials(part, ny, D, dcls, D, dcls, accumulate, st, T * D);
+  if (rc != VIT_OK || !dpos) return rc;
+  return launch_reduce_partials(part, ny, T * D, dpos, T * D, dpos, accumulate, st, T * D);
 }
 
 int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int dy_dtype, int rows, int cols, float dropout_p,
@@ -598,7 +630,7 @@ int vit_head_loss_bwd(vit_handle h, const float* last_hidden, const float* W, co
   return VIT_OK;
 }
 
-int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream) {
+static int grad_sqnorm_impl(vit_handle h, const float* g, int64_t n, float* out, int accumulate, vit_stream stream) {
   VIT_CHECK(g && out && n > 0, VIT_ERR_ARG, "vit_grad_sqnorm: bad arguments");
   const int blocks = grid_for(n / 4 + 1, 256, 1024);
   size_t wsb = 0;
@@ -607,9 +639,15 @@ int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_str
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(blocks), dim3(256), 0, st, g, (long)n, part);
   VIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(256), 0, st, part, blocks, out);
+  hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(256), 0, st, part, blocks, out, accumulate);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
+}
+int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream) {
+  return grad_sqnorm_impl(h, g, n, out, 0, stream);
+}
+int vit_grad_sqnorm_acc(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream) {
+  return grad_sqnorm_impl(h, g, n, out, 1, stream);
 }
 
 int vit_adamw_step(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,

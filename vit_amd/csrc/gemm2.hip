@@ -881,7 +881,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   {
     static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
-    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d>", at, bt, epi5);
+    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, g_pp_slots == 8 ? 8 : 10);
     else snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", geo[cfg][0], geo[cfg][1],
                   geo[cfg][2], geo[cfg][3], geo[cfg][4], at, bt, epi);
   }

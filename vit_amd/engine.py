@@ -395,7 +395,7 @@ class ViTEngine:
                                   self.cfg.layer_norm_eps, out=out, mean=mean, rstd=rstd)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dloss: torch.Tensor):
+    def backward(self, dloss: torch.Tensor, need_dx: bool = False):
         """Fill self.grads (every trainable slice exactly once) for the last forward; calls grad_ready_cb(lo, hi) as
         each bucket of the flat gradient buffer is complete (used to overlap the RCCL all-reduce)."""
         st = self._last
@@ -475,3 +475,11 @@ class ViTEngine:
                 out=self.g(e + "patch_embeddings.projection.weight").view(D, P), split_k=-1)
         if cb:
             cb(self.layout.embed_start, self.layout.embed_end)
+        if need_dx:
+            # gradient wrt the signal itself (a trainable input preprocessor sits in front): dpatches = dpatch Wp, then the
+            # overlap-add that undoes the tokenizer's unfold
+            S = c.stride
+            wp = self.w16(e + "patch_embeddings.projection.weight").view(D, P)
+            dpat = vf.gemm(t["dpatch"], wp, M=B * N, N=P, K=D, b_trans=True, out_dtype=torch.float32)
+            return vf.fold_add(dpat, B, c.image_size, P, S, N)
+        return None

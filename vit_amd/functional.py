@@ -202,6 +202,17 @@ def attention_probs(qkv, B: int, H: int, T: int, dh: int, scale: float):
 
 
 # ------------------------------------------------------------------------------------------------ embedding side
+def fold_add(dpatches, B: int, L: int, P: int, S: int, N: int, out=None):
+    """dx[B, L] = overlap-add of dpatches [B*N, P] (f32): the backward of unfold_cast wrt the signal."""
+    _chk(dpatches, torch.float32, "fold_add dpatches")
+    if dpatches.numel() != B * N * P:
+        raise _cabi.VitError("fold_add: dpatches must hold B*N*P elements")
+    out = out if out is not None else torch.empty((B, L), dtype=torch.float32, device=dpatches.device)
+    h = _h(dpatches)
+    check(h.lib.vit_fold_add(h.h, dpatches.data_ptr(), out.data_ptr(), B, L, P, S, N, _stream(dpatches)), "vit_fold_add")
+    return out
+
+
 def add_noise(flux, error, noise_level: float, seed: int, out=None):
     """flux + N(0,1) * error * noise_level (vit.py:86-88), counter-based normals keyed on (seed, element index)."""
     _chk(flux, torch.float32, "add_noise flux")
@@ -318,11 +329,13 @@ def head_loss_bwd(last_hidden, W, logits, labels, dloss, loss_kind: int, dlast=N
 
 
 # ------------------------------------------------------------------------------------------------ optimizer
-def grad_sqnorm(g, out=None):
+def grad_sqnorm(g, out=None, accumulate: bool = False):
+    """out[0] = sum g^2 (accumulate: += ), deterministic two-stage reduction."""
     _chk(g, torch.float32, "grad_sqnorm g")
     h = _h(g)
     out = out if out is not None else torch.empty(1, dtype=torch.float32, device=g.device)
-    check(h.lib.vit_grad_sqnorm(h.h, g.data_ptr(), g.numel(), out.data_ptr(), _stream(g)), "vit_grad_sqnorm")
+    fn = h.lib.vit_grad_sqnorm_acc if accumulate else h.lib.vit_grad_sqnorm
+    check(fn(h.h, g.data_ptr(), g.numel(), out.data_ptr(), _stream(g)), "vit_grad_sqnorm")
     return out
 
 

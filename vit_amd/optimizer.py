@@ -29,6 +29,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model = model
         params = [p for p in model.parameters()]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # parameters that are not slices of the engine's flat buffer (a trainable input preprocessor): same AdamW kernel,
+        # own moment buffers, and their gradients join the global clipping norm
+        own = {id(p) for p in getattr(model, "_param_list", [])}
+        self._extras = [p for p in params if id(p) not in own]
+        self._extra_state = {}
         self.adam_l2 = adam_l2
         self._m = None
         self._v = None
@@ -67,14 +72,24 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad.data_ptr() != gv.data_ptr():
                     gv.copy_(p.grad)
         sq = None
+        extras = [p for p in self._extras if p.grad is not None]
         if self._clip is not None:
             sq = vf.grad_sqnorm(eng.grads[:n], out=self._sq)
+            for p in extras:
+                vf.grad_sqnorm(p.grad.contiguous().view(-1), out=self._sq, accumulate=True)
             self.last_grad_norm = sq
         shadow = eng.shadow if eng.precision == "bf16" else None  # f32 mode has no bf16 copy to refresh
         vf.adamw_step(eng.flat, eng.grads, self._m, self._v, shadow, lr=float(g["lr"]), beta1=g["betas"][0],
                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step, sqnorm=sq,
                       max_norm=float(self._clip or 0.0), n=n)
         eng.mark_shadow_fresh()  # the kernel rewrote flat AND shadow through raw pointers
+        for p in extras:
+            st = self._extra_state.get(id(p))
+            if st is None or st[0].device != p.device:
+                st = self._extra_state[id(p)] = (torch.zeros_like(p.data).view(-1), torch.zeros_like(p.data).view(-1))
+            vf.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st[0], st[1], None, lr=float(g["lr"]),
+                          beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                          step=self._step, sqnorm=sq, max_norm=float(self._clip or 0.0))
         return loss
 
     def zero_grad(self, set_to_none: bool = True):

@@ -74,6 +74,7 @@ class _ViTFunction(torch.autograd.Function):
         eng = model.engine
         loss, logits, _, _ = eng.forward(x, labels, training=training, need_grad=True)
         ctx.model = model
+        ctx.need_dx = bool(x.requires_grad)  # a trainable input preprocessor in front of the ViT
         ctx.mark_non_differentiable(logits)
         return loss, logits
 
@@ -81,14 +82,14 @@ class _ViTFunction(torch.autograd.Function):
     def backward(ctx, dloss, _dlogits):
         model = ctx.model
         eng = model.engine
-        eng.backward(dloss)
+        dx = eng.backward(dloss, need_dx=ctx.need_dx)
         grads = []
         for name, p in zip(model._param_names, model._param_list):
             if not p.requires_grad or name.startswith("vit.pooler."):
                 grads.append(None)  # the pooler output is never used (specvit.py:78): no gradient, as in the reference
             else:
                 grads.append(eng.g(name))
-        return (None, None, None, None, *grads)
+        return (None, dx, None, None, *grads)
 
 
 class MyViT(nn.Module):
@@ -103,9 +104,7 @@ class MyViT(nn.Module):
         self.task_type = config.task_type
         if self.task_type not in ("cls", "reg"):
             raise ValueError(f"Unsupported task_type '{self.task_type}'")  # specvit.py:55
-        if preprocessor is not None:
-            raise NotImplementedError("input preprocessors (ZCA/PCA/attention) are a SURVEY section 8(f) 'next' row")
-        self.preprocessor = None
+        self.preprocessor = preprocessor  # specvit.py:43, 72-73: applied to pixel_values before the ViT
         self.engine = ViTEngine(config, loss_name=loss_name)
         self._loss_name = self.engine.loss_name
         self._model_name = build_model_name(config, model_name, full_config=full_config)
@@ -146,6 +145,8 @@ class MyViT(nn.Module):
         new_flat = fn(self.engine.flat)
         self.engine.rebind(new_flat)
         self._rebind_views()
+        if self.preprocessor is not None:
+            self.preprocessor._apply(fn)
         return self
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
@@ -181,6 +182,8 @@ class MyViT(nn.Module):
     def forward(self, pixel_values, labels=None, output_attentions=None, output_hidden_states=None, return_dict=None):
         eng = self.engine
         training = self.training
+        if self.preprocessor is not None:
+            pixel_values = self.preprocessor(pixel_values)
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self._param_list)
         if want_grad and not (output_attentions or output_hidden_states):
             loss, logits = _ViTFunction.apply(self, pixel_values, labels, training, *self._param_list)
@@ -206,11 +209,21 @@ class MyViT(nn.Module):
             log_fn({f"{self.loss_name}_loss": loss})
 
     def set_preprocessor_trainable(self, trainable: bool) -> None:
+        """specvit.py:118-130: freeze / unfreeze the input preprocessor."""
         if self.preprocessor is None:
             return
+        if hasattr(self.preprocessor, "set_qk_trainable"):
+            self.preprocessor.set_qk_trainable(trainable)
+        elif hasattr(self.preprocessor, "freeze"):
+            self.preprocessor.freeze(not trainable)
+        else:
+            for param in self.preprocessor.parameters():
+                param.requires_grad = trainable
 
     def set_precision(self, precision) -> str:
         """'32' (reference default; fp32-class kernels) or 'bf16-mixed' (bf16 MFMA operands): see ViTEngine."""
+        if self.preprocessor is not None and hasattr(self.preprocessor, "set_precision"):
+            self.preprocessor.set_precision(precision)
         return self.engine.set_precision(precision)
 
     # ------------------------------------------------------------------ extras used by the build's own trainer
