@@ -293,6 +293,40 @@ def make_rope():
     print(f"[rope] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def make_prep():
+    """Linear input preprocessors: the reference's compute_zca_matrix / compute_pca_matrix /
+    LinearPreprocessor (src/models/preprocessor.py) on a synthetic 48-dim covariance; tests compare the MI355X host
+    module's matrices and its kernel forward against these outputs."""
+    _import_reference()
+    from src.models.preprocessor import LinearPreprocessor, compute_pca_matrix, compute_zca_matrix
+
+    rng = np.random.Generator(np.random.PCG64(88))
+    Dm = 48
+    a = rng.standard_normal((Dm, 3 * Dm))
+    cov = torch.from_numpy((a @ a.T / (3 * Dm)).astype(np.float64))
+    cov = cov * torch.logspace(0, -3, Dm, dtype=torch.float64)[None, :] * torch.logspace(0, -3, Dm, dtype=torch.float64)[:, None]
+    lam, vec = torch.linalg.eigh(cov)
+    lam, vec = lam.flip(0).float(), vec.flip(1).float()          # descending, as the reference's cov files store them
+    mean = torch.from_numpy(rng.standard_normal(Dm).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((8, Dm)).astype(np.float32))
+    out = dict(eigvecs=vec.numpy(), eigvals=lam.numpy(), mean=mean.numpy(), x=x.numpy())
+    cases = {"zca_full_s1": dict(r=None, shrinkage=0.1), "zca_full_s0": dict(r=None, shrinkage=0.0),
+             "zca_r16_s2": dict(r=16, shrinkage=0.2), "zca_r40_s0": dict(r=40, shrinkage=0.0)}
+    for k, kw in cases.items():
+        out[k] = compute_zca_matrix(vec, lam, eps=1e-5, **kw).numpy()
+    out["pca_r16"] = compute_pca_matrix(vec, r=16).numpy()
+    out["pca_full"] = compute_pca_matrix(vec, r=None).numpy()
+    P = torch.from_numpy(out["zca_r16_s2"])
+    bias = -mean @ P.t()                                          # builder.py:66-68
+    with torch.no_grad():
+        out["y_zca_r16_s2"] = LinearPreprocessor(P, bias=bias, freeze=True)(x).numpy()
+        Pp = torch.from_numpy(out["pca_r16"])
+        out["y_pca_r16"] = LinearPreprocessor(Pp, bias=-mean @ Pp.t(), freeze=True)(x).numpy()
+    path = os.path.join(ROOT, "tests", "golden", "prep.npz")
+    np.savez_compressed(path, **out)
+    print(f"[prep] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -313,6 +347,7 @@ def main():
                           stride_size=32, task_type="cls", num_labels=5, pos_encoding_type="learned", loss_name="ce")
     make_one("k1", k1, "log_g", 6, 41, 42, True)
     make_rope()
+    make_prep()
 
 
 if __name__ == "__main__":

@@ -188,3 +188,24 @@ def test_oracle_rope_matches_reference_module():
     with torch.no_grad():
         out0 = refvit.forward(rc0, sd, torch.from_numpy(g["p1_flux"]), torch.from_numpy(g["p1_labels"]))
     assert rel(out0.logits, g["p1_logits"]) > 1e-3
+
+
+def test_preprocessor_matrices_match_reference():
+    """vit_amd.preprocessor's ZCA / PCA builders against the reference's compute_zca_matrix / compute_pca_matrix outputs
+    (tests/golden/prep.npz, written by oracle/make_golden.py): full rank with and without shrinkage, low rank with the
+    tail-median perpendicular scaling, PCA truncation; plus the LinearPreprocessor surface (freeze <-> parameters)."""
+    from vit_amd.preprocessor import LinearPreprocessor, compute_pca_matrix, compute_zca_matrix
+
+    g = np.load(os.path.join(GOLD, "prep.npz"))
+    vec, lam = torch.from_numpy(g["eigvecs"]), torch.from_numpy(g["eigvals"])
+    for key, kw in {"zca_full_s1": dict(r=None, shrinkage=0.1), "zca_full_s0": dict(r=None, shrinkage=0.0),
+                    "zca_r16_s2": dict(r=16, shrinkage=0.2), "zca_r40_s0": dict(r=40, shrinkage=0.0)}.items():
+        assert rel(compute_zca_matrix(vec, lam, eps=1e-5, **kw), g[key]) < 1e-6, key
+    assert np.array_equal(compute_pca_matrix(vec, r=16).numpy(), g["pca_r16"])
+    assert np.array_equal(compute_pca_matrix(vec, r=None).numpy(), g["pca_full"])
+    pre = LinearPreprocessor(torch.from_numpy(g["pca_r16"]), bias=torch.zeros(16), freeze=True)
+    assert list(pre.parameters()) == [] and sorted(pre.state_dict()) == ["linear.bias", "linear.weight"]
+    pre.freeze(False)
+    assert sorted(n for n, _ in pre.named_parameters()) == ["linear.bias", "linear.weight"]
+    pre.freeze(True)
+    assert list(pre.parameters()) == [] and pre.out_features == 16

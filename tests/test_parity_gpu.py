@@ -427,3 +427,80 @@ def test_padded_rows_do_not_leak(dev, precision):
             else:
                 cos = float(torch.dot(mine.flatten().double(), g.flatten().double()) / (mine.double().norm() * g.double().norm()))
                 assert cos > 0.995, (name, B, cos)
+
+
+# ------------------------------------------------------------------ linear input preprocessors
+def test_linear_preprocessor_forward_matches_reference(dev):
+    """LinearPreprocessor forward (one vit_gemm) against the reference module's outputs in tests/golden/prep.npz."""
+    from vit_amd.preprocessor import LinearPreprocessor
+
+    g = np.load(os.path.join(GOLD, "prep.npz"))
+    x, mean = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["mean"])
+    for key in ("zca_r16_s2", "pca_r16"):
+        P = torch.from_numpy(g[key])
+        pre = LinearPreprocessor(P, bias=-mean @ P.t(), freeze=True).to(dev)
+        assert rel(pre(x), torch.from_numpy(g["y_" + key])) < 2e-5
+        pre.set_precision("bf16-mixed")
+        assert rel(pre(x), torch.from_numpy(g["y_" + key])) < 1.5e-2
+
+
+@pytest.mark.parametrize("stride", [16, 8])
+def test_trainable_preprocessor_gradients_and_step(dev, stride):
+    """A TRAINABLE preprocessor in front of the ViT (freeze_epochs = 0): the gradient reaches it through the patch
+    projection and the overlap-add that undoes the tokenizer's unfold (vit_fold_add; stride 8 < patch 16 overlaps);
+    dP, dbias and every model gradient against autograd over the oracle, then one clipped AdamW step of everything."""
+    import torch.nn.functional as F
+    from oracle import refvit
+    from vit_amd.config import ViTConfig
+    from vit_amd.optimizer import FusedAdamW
+    from vit_amd.preprocessor import LinearPreprocessor
+    from vit_amd.specvit import MyViT
+
+    L_in, r = 96, 64
+    rc = refvit.RefConfig(image_size=r, patch_size=16, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                          stride_size=stride, loss_name="mae")
+    sd = refvit.make_state_dict(rc, 71)
+    gen = torch.Generator().manual_seed(72)
+    P0 = torch.randn(r, L_in, generator=gen) / L_in ** 0.5
+    b0 = torch.randn(r, generator=gen) * 0.1
+    x = torch.randn(5, L_in, generator=gen)
+    labels = torch.rand(5, generator=gen)
+
+    # oracle: F.linear in front of the restated model (specvit.py:72-73), autograd, clip 0.5, AdamW lr 1e-3
+    Pr, br = P0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = refvit.forward(rc, params, F.linear(x, Pr, br), labels)
+    out_ref.loss.backward()
+    every = [p for p in params.values() if p.grad is not None] + [Pr, br]
+    ref_grads = {id(p): p.grad.clone() for p in every}
+    ref_norm = float(torch.nn.utils.clip_grad_norm_(every, 0.5))
+    opt_ref = torch.optim.AdamW(every, lr=1e-3, weight_decay=0.0)
+    opt_ref.step()
+
+    cfg = ViTConfig(task_type="reg", image_size=r, patch_size=16, hidden_size=32, num_hidden_layers=2,
+                    num_attention_heads=2, stride_size=stride)
+    pre = LinearPreprocessor(P0.clone(), bias=b0.clone(), freeze=False)
+    model = MyViT(cfg, loss_name="mae", preprocessor=pre)
+    model.set_precision("32")
+    model.load_state_dict({**sd, "preprocessor.linear.weight": P0, "preprocessor.linear.bias": b0}, strict=True)
+    model = model.to(dev).eval()
+    assert pre.linear.weight.is_cuda and isinstance(pre.linear.weight, torch.nn.Parameter)
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.set_grad_clip(0.5)
+    out = model(x.to(dev), labels=labels.to(dev))
+    assert rel(out.logits, out_ref.logits.detach()) < 1e-4
+    out.loss.backward()
+    assert rel(pre.linear.weight.grad, ref_grads[id(Pr)]) < 3e-4
+    assert rel(pre.linear.bias.grad, ref_grads[id(br)]) < 3e-4
+    for name, p in model.named_parameters():
+        if name in params and params[name].grad is not None and float(ref_grads[id(params[name])].norm()) > 1e-6:
+            assert rel(p.grad.reshape(params[name].shape), ref_grads[id(params[name])]) < 3e-4, name
+    opt.step()
+    assert abs(float(opt.last_grad_norm.sqrt()) - ref_norm) < 2e-4 * ref_norm
+    assert rel(pre.linear.weight.detach(), Pr.detach()) < 1e-5 and rel(pre.linear.bias.detach(), br.detach()) < 1e-4
+    moved = float((pre.linear.weight.detach().cpu() - P0).abs().max())
+    assert moved > 1e-4  # the preprocessor really was updated
+    # frozen again: no parameters, no input gradient requested
+    model.set_preprocessor_trainable(False)
+    assert [n for n, _ in model.named_parameters() if n.startswith("preprocessor")] == []
+    model(x.to(dev), labels=labels.to(dev)).loss.backward()

@@ -107,6 +107,15 @@ class Trainer:
             eng.grad_ready_cb = self.reducer.bucket_ready
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.set_grad_clip(self.gradient_clip_val)
+        # PreprocessorFreezeCallback (src/prepca/callbacks.py): warmup.freeze_epochs > 0 freezes the input preprocessor for
+        # that many epochs, -1 for good, 0 never.  (As in the reference, the optimizer was built from the parameters that
+        # existed at configure time: a preprocessor unfrozen later becomes trainable for autograd but is only stepped if
+        # the optimizer is rebuilt.)
+        warm = (getattr(module, "config", {}) or {}).get("warmup", {}) or {}
+        self.freeze_epochs = int(warm.get("freeze_epochs", 0) or 0)
+        self._unfrozen = False
+        if self.freeze_epochs != 0 and hasattr(module.model, "set_preprocessor_trainable"):
+            module.model.set_preprocessor_trainable(False)
 
     def training_step(self, module, batch, batch_idx):
         """One optimisation step with the reference's ordering."""
@@ -115,6 +124,10 @@ class Trainer:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
+            for p in getattr(self.optimizer, "_extras", []):  # a trainable preprocessor lives outside the flat buffer
+                if p.grad is not None:
+                    torch.distributed.all_reduce(p.grad, op=torch.distributed.ReduceOp.SUM)
+                    p.grad.div_(self.world)
         if not isinstance(self.optimizer, FusedAdamW) and self.gradient_clip_val:
             torch.nn.utils.clip_grad_norm_([p for p in module.parameters() if p.grad is not None], self.gradient_clip_val)
         self.optimizer.step()
@@ -161,6 +174,12 @@ class Trainer:
         epochs = 1 if self.fast_dev_run else self.max_epochs
         for epoch in range(epochs):
             self.current_epoch = module.current_epoch = epoch
+            if self.freeze_epochs > 0 and epoch >= self.freeze_epochs and not self._unfrozen and \
+                    hasattr(module.model, "set_preprocessor_trainable"):
+                module.model.set_preprocessor_trainable(True)  # callbacks.py:31-46
+                self._unfrozen = True
+                if self.verbose:
+                    print(f"[trainer] epoch {epoch}: unfreezing the input preprocessor")
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
             module.train()
