@@ -209,3 +209,26 @@ def test_preprocessor_matrices_match_reference():
     assert sorted(n for n, _ in pre.named_parameters()) == ["linear.bias", "linear.weight"]
     pre.freeze(True)
     assert list(pre.parameters()) == [] and pre.out_features == 16
+
+
+def test_spec_dataset_contract():
+    """vit_amd.data.SpecDataset: clip at zero, min-max labels with the training split's statistics re-used, fixed-seed
+    validation noise (torch.manual_seed(42) -> randn_like * error * level, base.py:312-326), 3- vs 4-tuples."""
+    from vit_amd.data import SpecDataset, SpecLoader
+
+    g = torch.Generator().manual_seed(5)
+    flux, err = torch.randn(40, 64, generator=g), torch.rand(40, 64, generator=g) * 0.1
+    logg = torch.rand(40, generator=g) * 5
+    tr = SpecDataset(flux, err, logg, task="reg", stage="train", label_norm="minmax", noise_level=0.5)
+    assert float(tr.flux.min()) >= 0.0 and torch.equal(tr.flux, flux.clip(min=0))
+    assert float(tr.labels.min()) == 0.0 and abs(float(tr.labels.max()) - 1.0) < 1e-6 and len(tr[0]) == 3
+    va = SpecDataset(flux[:10], err[:10], logg[:10] + 1.0, task="reg", stage="val", label_norm="minmax",
+                     noise_level=0.5, stats=tr.stats)
+    assert torch.allclose(va.labels, (logg[:10] + 1.0 - logg.min()) / (logg.max() - logg.min()))
+    torch.manual_seed(42)
+    expect = va.flux + torch.randn_like(va.flux) * va.error * 0.5
+    assert torch.equal(va.noisy, expect) and len(va[0]) == 4 and torch.equal(va[3][0], expect[3])
+    cl = SpecDataset(flux, err, logg, task="cls", stage="train")
+    assert cl.labels.dtype == torch.int64 and torch.equal(cl.labels, (logg > 2.5).long())
+    batches = list(SpecLoader(tr, 16, shuffle=True, seed=1))
+    assert sum(b[0].shape[0] for b in batches) == 40 and batches[0][0].shape == (16, 64)
