@@ -157,6 +157,12 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
 int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                       float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
                       float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
+/* Same, and dqkv_colsum (f32 [3*H*dh]) = the column sums of dqkv as stored: the bias gradient of the fused QKV projection
+ * (without RoPE; with it the sums must be taken after the inverse rotation).  The resident bf16 kernels sum their own rows
+ * on the way out (one partial row per wave through the workspace); other paths run vit_colsum afterwards. */
+int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                             float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                             float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream);
 /* Attention probabilities [B, H, T, T] f32 (eval-mode, for output_attentions=True: specvit.py:92-93). */
 int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtype, int B, int H, int T, int dh,
                         float scale, vit_stream stream);

@@ -619,3 +619,28 @@ def test_gemm_gelu_grad_and_mul_aux(dev, core, dt):
     tol = 6e-3 if dt == torch.bfloat16 else 2e-5
     assert rel(y, ref.detach()) < tol
     assert rel(dU, pre.grad) < (8e-3 if dt == torch.bfloat16 else 3e-5)
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(3, 2, 129, 16), (4, 3, 197, 64), (2, 4, 50, 32)])
+def test_attention_bwd_fused_colsum(dev, B, H, T, dh):
+    """vit_attention_bwd_colsum: the per-wave column sums the resident kernels emit, reduced over the batch, must equal
+    vit_colsum over the stored dqkv (same bf16-rounded values, f32 sums), with and without dropout, for 1 and 2
+    workgroups per head."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    D = H * dh
+    qkv = bf(randn((B * T, 3 * D), dev, 140, 0.5))
+    dctx = bf(randn((B * T, D), dev, 141, 0.5))
+    for split in (1, 2):
+        _cabi.set_option("attn_split", split)
+        try:
+            for drop in ((0.0, 0, 0), (0.1, 9, 3)):
+                ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, dh ** -0.5, dropout=drop)
+                ref = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=drop)
+                cs = torch.empty(3 * D, device=dev)
+                out = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=drop, colsum_out=cs)
+                assert torch.equal(out, ref)
+                assert rel(cs, vf.colsum(ref)) < 1e-5
+        finally:
+            _cabi.set_option("attn_split", 2)

@@ -22,6 +22,8 @@
 
 namespace vit {
 
+void* ctx_workspace(vit_handle h, size_t* bytes);
+
 constexpr int AW = 4;    // waves per workgroup
 constexpr int RT = 64;   // rows per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -34,6 +36,7 @@ struct AttnArgs {
   float scale;
   DropCfg drop;
   int nsplit, wpw;  // resident kernels: workgroups per (batch, head) and waves per workgroup (row tiles are dealt in order)
+  float* csum_part;  // resident backward kernels: [B * nsplit * wpw][3 * H * dh] per-wave column sums of dqkv as stored, or NULL
 };
 
 template <int DH>
@@ -446,6 +449,21 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict
 // LDS-read and barrier bound at ~135 TFLOP/s).
 // Stage two [T, dh] matrices (all their 64-row tiles) at once: every global load of a thread is issued before its first
 // LDS store, so a workgroup pays ONE memory latency for its whole working set (a load->store loop paid ten).
+// column sums of a wave's 16-row x 4-column register tile over its rows (lanes that share lane >> 4), bf16-rounded like
+// the stored values; the four lanes with l15 == 0 hold the result
+__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) {
+    v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64);
+    v[2] += __shfl_xor(v[2], m, 64); v[3] += __shfl_xor(v[3], m, 64);
+  }
+  return v;
+}
+__device__ __forceinline__ f32x4 bf_round4(u32x2 pk) {
+  return (f32x4){__builtin_bit_cast(float, pk[0] << 16), __builtin_bit_cast(float, pk[0] & 0xFFFF0000u),
+                 __builtin_bit_cast(float, pk[1] << 16), __builtin_bit_cast(float, pk[1] & 0xFFFF0000u)};
+}
+
 template <int DH>
 __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, long lda, char* imgB, const short* gb,
                                                 long ldb, int T, int dh, int ntl, int tid, int nthr) {
@@ -626,7 +644,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
   __syncthreads();
   const int q00 = (part * p.wpw + wave) * RQ * 16;
-  if (q00 >= T) return;
+  float* csum = p.csum_part ? p.csum_part + ((long)(bh / p.H) * p.nsplit * p.wpw + part * p.wpw + wave) * ld + h * dh : nullptr;
+  if (q00 >= T) {
+    if (csum && lane < DH / 4 && lane * 4 < dh) *(f32x4*)(csum + lane * 4) = zero4();  // an idle wave's partial row
+    return;
+  }
 
   bf16x8 qf[RQ][DH / 32], dof[RQ][DH / 32];
   float lse2[RQ], del[RQ];
@@ -712,6 +734,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
       }
     }
   }
+  f32x4 cs[DH / 16];
+#pragma unroll
+  for (int dt = 0; dt < DH / 16; ++dt) cs[dt] = zero4();
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
     const int q = q00 + rq * 16 + l15;
@@ -724,8 +749,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
           const f32x4 v = dqt[rq][dt] * p.scale;
           u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *(u32x2*)(o + d) = pk;
+          cs[dt] += bf_round4(pk);
         }
       }
+    }
+  }
+  if (csum) {  // the query third's bias gradient: this wave's rows, reduced over the batch afterwards
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 t = rows16_sum(cs[dt]);
+      const int d = dt * 16 + lg * 4;
+      if (l15 == 0 && d < dh) *(f32x4*)(csum + d) = t;
     }
   }
 }
@@ -753,7 +787,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   }
   __syncthreads();
   const int k00 = (part * p.wpw + wave) * RQ * 16;
-  if (k00 >= T) return;
+  float* csum = p.csum_part ? p.csum_part + ((long)(bh / p.H) * p.nsplit * p.wpw + part * p.wpw + wave) * ld + p.H * dh + h * dh
+                            : nullptr;
+  if (k00 >= T) {
+    if (csum && lane < DH / 4 && lane * 4 < dh) {
+      *(f32x4*)(csum + lane * 4) = zero4();
+      *(f32x4*)(csum + p.H * dh + lane * 4) = zero4();
+    }
+    return;
+  }
 
   bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
   f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
@@ -839,6 +881,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
       }
     }
   }
+  f32x4 csk[DH / 16], csv[DH / 16];
+#pragma unroll
+  for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
     const int key = k00 + rq * 16 + l15;
@@ -854,7 +899,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
           u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *(u32x2*)(ok + d) = pk;
           *(u32x2*)(ov + d) = pv;
+          csk[dt] += bf_round4(pk);
+          csv[dt] += bf_round4(pv);
         }
+      }
+    }
+  }
+  if (csum) {  // the key and value thirds' bias gradients
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
+      const int d = dt * 16 + lg * 4;
+      if (l15 == 0 && d < dh) {
+        *(f32x4*)(csum + d) = tk;
+        *(f32x4*)(csum + p.H * dh + d) = tv;
       }
     }
   }
@@ -862,6 +920,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
 
 constexpr int RES_MAX_T = 256, RES_MAX_DH = 64, RES_RQ = 2;
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
+
+static void res_geometry(int T, int* nsplit, int* wpw) {
+  const int nq = cdiv(T, 16), nw = cdiv(nq, RES_RQ);
+  *nsplit = std::max(1, std::min(g_attn_split, nw));
+  *wpw = cdiv(nw, *nsplit);
+  *nsplit = cdiv(nw, *wpw);
+}
 
 template <typename F>
 static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
@@ -874,11 +939,8 @@ static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
   // several workgroups per (batch, head), each staging the whole K / V (or Q / dO) but owning a share of the row tiles:
   // with 4-wave workgroups three of them fit a CU (150 KiB of LDS, 12 of the 12 wave slots 152 VGPRs leave), so the
   // staging latency of one hides behind the key loops of the others; one 7-wave workgroup per CU paid it in the open.
-  const int nq = cdiv(a.T, 16), nw = cdiv(nq, RES_RQ);
   AttnArgs b = a;
-  b.nsplit = std::max(1, std::min(g_attn_split, nw));
-  b.wpw = cdiv(nw, b.nsplit);
-  b.nsplit = cdiv(nw, b.wpw);
+  res_geometry(a.T, &b.nsplit, &b.wpw);
   hipLaunchKernelGGL(fn, dim3(a.B * a.H * b.nsplit), dim3(b.wpw * 64), smem, st, b);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
@@ -1110,9 +1172,45 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
   return VIT_OK;
 }
 
+static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                              float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream);
+
 int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                       float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
                       float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
+  return attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site, nullptr,
+                            stream);
+}
+
+int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                             float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                             float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream) {
+  VIT_CHECK(dqkv_colsum, VIT_ERR_ARG, "vit_attention_bwd_colsum: null dqkv_colsum");
+  const int D3 = 3 * H * dh;
+  if (io_dtype == VIT_BF16 && T <= RES_MAX_T && dh <= RES_MAX_DH && (dh % 4) == 0) {
+    int nsplit, wpw;
+    res_geometry(T, &nsplit, &wpw);
+    size_t wsb = 0;
+    float* part = (float*)ctx_workspace(h, &wsb);
+    const int prow = B * nsplit * wpw;
+    if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
+      // the resident kernels leave one partial row per wave: column sums of what they stored
+      int rc = attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+                                  part, stream);
+      if (rc != VIT_OK) return rc;
+      return launch_reduce_partials(part, prow, D3, dqkv_colsum, D3, dqkv_colsum, 0, (hipStream_t)stream);
+    }
+  }
+  int rc = attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+                              nullptr, stream);
+  if (rc != VIT_OK) return rc;
+  return vit_colsum(h, dqkv, io_dtype, D3, dqkv_colsum, B * T, D3, 0, stream);
+}
+
+static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
+                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                              float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && ctx && dctx && lse && delta && dqkv, VIT_ERR_ARG, "vit_attention_bwd: null pointer");
   int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
@@ -1133,6 +1231,7 @@ int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
+  a.csum_part = colsum_part;
   if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
     const size_t ntl = cdiv(T, RT);
     DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * ntl * RT * DH_ * 2), st, rc);

@@ -157,9 +157,11 @@ constexpr unsigned OOB = 0x80000000u;  // any voffset >= num_records reads as ze
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// out[c] (+)= sum_{k < nblk} part[k * width + c]; columns [0, split) go to out0, [split, width) to out1 (- split).
-// 64 columns x 16 row groups per block, fixed summation order (deterministic).  Defined in elementwise.hip.
+// out[c] (+)= sum_{k < nblk} part[k * stride + c]; columns [0, split) go to out0, [split, split2) to out1 (- split),
+// [split2, width) to out2 (- split2; split2 = 0: no third output).  64 columns x 16 row groups per block, fixed
+// summation order (deterministic).  Defined in elementwise.hip.
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
-                           hipStream_t st, int stride = 0 /* floats between partial rows; 0 = width */);
+                           hipStream_t st, int stride = 0 /* floats between partial rows; 0 = width */, int split2 = 0,
+                           float* out2 = nullptr);
 
 }  // namespace vit

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const void* __restri
 }
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int width,
                                                                float* __restrict__ out0, int split,
-                                                               float* __restrict__ out1, int accumulate, int stride) {
+                                                               float* __restrict__ out1, int accumulate, int stride,
+                                                               int split2, float* __restrict__ out2) {
   __shared__ float red[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -171,16 +172,17 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s += red[k][tx];
-    float* o = c < split ? out0 + c : out1 + (c - split);
+    // columns [0, split) -> out0, [split, split2) -> out1, [split2, width) -> out2
+    float* o = c < split ? out0 + c : (c < split2 ? out1 + (c - split) : out2 + (c - split2));
     if (accumulate) s += *o;
     *o = s;
   }
 }
 
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
-                           hipStream_t st, int stride) {
+                           hipStream_t st, int stride, int split2, float* out2) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(width, 64)), dim3(1024), 0, st, part, nblk, width, out0, split,
-                     out1, accumulate, stride ? stride : width);
+                     out1, accumulate, stride ? stride : width, split2 > 0 ? split2 : width, out2);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

@@ -237,9 +237,8 @@ static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float
   else rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
                                  : ln_bwd_dispatch<0, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
   if (rc != VIT_OK) return rc;
-  rc = launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st, np * D);
-  if (rc != VIT_OK || !dyn) return rc;
-  return launch_reduce_partials(part + 2 * D, blocks, D, dbias, D, dbias, 0, st, np * D);
+  if (!dyn) return launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st, np * D);
+  return launch_reduce_partials(part, blocks, 3 * D, dgamma, D, dbeta, 0, st, np * D, 2 * D, dbias);  // one launch for all three
 }
 
 }  // namespace vit

@@ -444,11 +444,14 @@ class ViTEngine:
             vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, b_trans=True, out=t["dctx"])
+            # the QKV bias gradient = column sums of dqkv: taken by the attention kernels on their way out, unless RoPE
+            # sits in between (then after the inverse rotation, by the column-sum kernel)
             vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
-                             dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"])
+                             dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"],
+                             colsum_out=None if rope is not None else self._qkv_bias(i, self.grads))
             if rope is not None:  # gradient wrt the un-rotated q, k: the inverse rotation
                 vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
-            vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
+                vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
             vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
                     split_k=-1)
             vf.gemm(t["dqkv"], self._qkv16(i), M=Mp, N=D, K=3 * D, b_trans=True, out=t["dh"])

@@ -181,12 +181,20 @@ def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: D
 
 
 def attention_bwd(qkv, ctx, dctx, lse, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP,
-                  dqkv=None, delta=None):
+                  dqkv=None, delta=None, colsum_out=None):
+    """colsum_out (f32 [3*H*dh]): also the column sums of dqkv (the QKV projection's bias gradient)."""
     _chk(dctx, qkv.dtype, "attention_bwd dctx")
     h = _h(qkv)
     dqkv = dqkv if dqkv is not None else torch.empty_like(qkv)
     delta = delta if delta is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
     p, seed, site = dropout
+    if colsum_out is not None:
+        _chk(colsum_out, torch.float32, "attention_bwd colsum_out")
+        h.ensure_workspace(B * 16 * 3 * H * dh * 4)
+        check(h.lib.vit_attention_bwd_colsum(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
+                                             delta.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed,
+                                             site, colsum_out.data_ptr(), _stream(qkv)), "vit_attention_bwd_colsum")
+        return dqkv
     check(h.lib.vit_attention_bwd(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                   dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed, site, _stream(qkv)),
           "vit_attention_bwd")
