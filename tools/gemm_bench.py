@@ -21,10 +21,12 @@ def main():
     ap.add_argument("--M", type=int, default=50432)
     args = ap.parse_args()
     cores = [c for c in args.cores.split(",")]  # "5" or "5s8" / "5s10": ping-pong core with an 8- / 10-slot ring
-    def select(c):
-        core, _, slots = c.partition("s")
+    def select(c):  # "5", "5s10" (10-slot ring), "5b0" (always 256 workgroups)
+        core, _, bal = c.partition("b")
+        core, _, slots = core.partition("s")
         _cabi.set_option("gemm_core", int(core))
         _cabi.set_option("gemm_pp_slots", int(slots) if slots else 8)
+        _cabi.set_option("gemm_balance_wgs", int(bal) if bal else 1)
     dev = torch.device("cuda:0")
     M, D, F = args.M, 768, 3072
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -70,6 +72,7 @@ def main():
                     times[name][c].append(e0.elapsed_time(e1) / 3)
     _cabi.set_option("gemm_core", 1)
     _cabi.set_option("gemm_pp_slots", 8)
+    _cabi.set_option("gemm_balance_wgs", 1)
     tot = {c: 0.0 for c in cores}
     print(f"{'case':48s} " + " ".join(f"core{c}: us / TF".rjust(20) for c in cores))
     for name, (fn, fl) in cases.items():

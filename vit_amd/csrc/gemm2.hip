@@ -742,6 +742,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #undef PP_STAGE_X
 }
 
+int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
 int g_pp_slots = 8;  // vit_set_option("gemm_pp_slots"): half-tile slots of the ping-pong ring, 8 (default) or 10
 template <int AT, int BT, int EPI, int NSLOT>
 static int launch_stag_n(const Gemm2Args& a, dim3 grid, hipStream_t st) {
@@ -843,6 +844,12 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.slab = (float*)ws;
   }
   a.nblk = std::min(ntile, slots);
+  if (cfg == 5 && g_balance_wgs && ntile > slots) {
+    // multi-round persistent walk: the makespan is ceil(ntile / slots) tile-times whatever the workgroup count, so launch
+    // just enough workgroups for that many rounds (591 tiles -> 197 workgroups x 3 instead of 256 of which 177 idle a
+    // third of the time): the idle CUs' power budget goes to the busy ones' clock, and L2 / fabric see less contention
+    a.nblk = cdiv(ntile, cdiv(ntile, slots));
+  }
   a.bias = d->bias;
   a.aux_in = (const short*)d->aux_in; a.aux_out = (short*)d->aux_out; a.ldaux = d->ldaux;
   a.residual = d->residual; a.ldres = d->ldres;
