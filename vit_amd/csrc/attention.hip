@@ -466,9 +466,9 @@ __device__ __forceinline__ f32x4 bf_round4(u32x2 pk) {
 
 template <int DH>
 __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, long lda, char* imgB, const short* gb,
-                                                long ldb, int T, int dh, int ntl, int tid, int nthr) {
+                                                long ldb, int T, int dh, int rows_alloc, int tid, int nthr) {
   constexpr int CPR = DH / 8, MAXI = 8;
-  const int total = ntl * RT * CPR;
+  const int total = rows_alloc * CPR;  // rows staged (zero beyond T): a multiple of 16, not necessarily of the 64-row tile
   for (int base = 0; base < total; base += MAXI * nthr) {
     i32x4 va[MAXI], vb[MAXI];
 #pragma unroll
@@ -506,8 +506,11 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   const short* kb_ = qb + p.H * dh;
   const short* vb = kb_ + p.H * dh;
   char* Kimg = smem;
-  char* Vimg = smem + ntl * TILE;
-  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
+  // only the 16-row blocks that hold keys are staged: 208 rows at T = 197 -> 52 KiB per workgroup, so THREE workgroups
+  // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
+  const int rows_alloc = (T + 15) & ~15;
+  char* Vimg = smem + rows_alloc * (DH * 2);
+  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
   __syncthreads();
   const int q00 = (part * p.wpw + wave) * RQ * 16;
   if (q00 >= T) return;  // no barrier after this point
@@ -597,7 +600,8 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
         for (int rq = 0; rq < RQ; ++rq) pf[rq] = pack8(st[rq][2 * u], st[rq][2 * u + 1]);
 #pragma unroll
         for (int dt = 0; dt < DH / 16; ++dt) {
-          const bf16x8 vf = frag_cols<DH>(Vt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+          // a 16-row block with no key in it is not staged: point its half of the fragment at the first block (its P is 0)
+          const bf16x8 vf = frag_cols<DH>(Vt, u * 32, (kb + u * 32 + 16 < T) ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq)
             ot[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rq], ot[rq][dt], 0, 0, 0);
@@ -640,8 +644,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   const short* dob = p.dctx + (long)b * T * ldc + h * dh;
   const short* ob = p.ctx + (long)b * T * ldc + h * dh;
   char* Kimg = smem;
-  char* Vimg = smem + ntl * TILE;
-  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, ntl, tid, blockDim.x);
+  // only the 16-row blocks that hold keys are staged: 208 rows at T = 197 -> 52 KiB per workgroup, so THREE workgroups
+  // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
+  const int rows_alloc = (T + 15) & ~15;
+  char* Vimg = smem + rows_alloc * (DH * 2);
+  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
   __syncthreads();
   const int q00 = (part * p.wpw + wave) * RQ * 16;
   float* csum = p.csum_part ? p.csum_part + ((long)(bh / p.H) * p.nsplit * p.wpw + part * p.wpw + wave) * ld + h * dh : nullptr;
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
       for (int rq = 0; rq < RQ; ++rq) df[rq] = pack8(ds[rq][0], ds[rq][1]);
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        const bf16x8 ktf = frag_cols<DH>(Kt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+        const bf16x8 ktf = frag_cols<DH>(Kt, u * 32, (kb + u * 32 + 16 < T) ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq)
           dqt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, df[rq], dqt[rq][dt], 0, 0, 0);
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   char* Oimg = smem + ntl * TILE;
   float* lse_s = (float*)(smem + 2 * ntl * TILE);
   float* del_s = lse_s + ntl * RT;
-  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, ntl, tid, blockDim.x);
+  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, ntl * RT, tid, blockDim.x);
   for (int i = tid; i < ntl * RT; i += blockDim.x) {
     lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
     del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
@@ -1163,7 +1170,7 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
   a.drop = make_drop(dropout_p, seed, site);
   if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
     const size_t ntl = cdiv(T, RT);
-    DISPATCH_RES(attn_fwd_res_kernel, a, (2 * ntl * RT * DH_ * 2), (hipStream_t)stream, rc);
+    DISPATCH_RES(attn_fwd_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), (hipStream_t)stream, rc);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
@@ -1234,7 +1241,7 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.csum_part = colsum_part;
   if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
     const size_t ntl = cdiv(T, RT);
-    DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * ntl * RT * DH_ * 2), st, rc);
+    DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
     DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * ntl * RT * DH_ * 2 + 2 * ntl * RT * 4), st, rc);
     return rc;
