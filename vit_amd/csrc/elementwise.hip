@@ -179,10 +179,42 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   }
 }
 
+// stage 1 of a tall reduction: blockIdx.y owns rows [y * chunk, (y + 1) * chunk) and leaves their sum IN its first row
+// (only this block touches those rows of its 64 columns); 64 columns x 16 row groups per block like the final stage
+__global__ __launch_bounds__(1024) void reduce_partials_stage1_kernel(float* __restrict__ part, int nblk, int width,
+                                                                      int stride, int chunk) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * chunk, r1 = min(nblk, r0 + chunk);
+  float a = 0.f;
+  if (c < width)
+    for (int k = r0 + ty; k < r1; k += 16) a += part[(long)k * stride + c];
+  red[ty][tx] = a;
+  __syncthreads();
+  if (ty == 0 && c < width) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_ += red[k][tx];
+    part[(long)r0 * stride + c] = s_;
+  }
+}
+
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
                            hipStream_t st, int stride, int split2, float* out2) {
+  if (!stride) stride = width;
+  if (nblk >= 256) {
+    // a tall partial matrix (one row per wave of the attention backward, per block of the LayerNorm backward): 36 blocks
+    // of one launch left most CUs idle; fold groups of rows first, in place, then reduce the group sums (fixed order)
+    const int groups = std::min(32, nblk / 32), chunk = cdiv(nblk, groups);
+    hipLaunchKernelGGL(reduce_partials_stage1_kernel, dim3(cdiv(width, 64), cdiv(nblk, chunk)), dim3(1024), 0, st,
+                       const_cast<float*>(part), nblk, width, stride, chunk);
+    VIT_LAUNCH_CHECK();
+    nblk = cdiv(nblk, chunk);
+    stride *= chunk;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(width, 64)), dim3(1024), 0, st, part, nblk, width, out0, split,
-                     out1, accumulate, stride ? stride : width, split2 > 0 ? split2 : width, out2);
+                     out1, accumulate, stride, split2 > 0 ? split2 : width, out2);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
