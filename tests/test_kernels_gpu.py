@@ -644,3 +644,30 @@ def test_attention_bwd_fused_colsum(dev, B, H, T, dh):
                 assert rel(cs, vf.colsum(ref)) < 1e-5
         finally:
             _cabi.set_option("attn_split", 2)
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 100, 768, 256), (256 * 197, 768, 768), (256 * 90, 1024, 512)])
+def test_gemm_half_tile_tail(dev, M, N, K):
+    """Tile counts that leave a partial last round (300, 591, 360 tiles on 256 workgroups): those tiles run in a second
+    launch as half tiles (two workgroups per tile, two phases per K-tile).  Same products in the same order per element:
+    the outputs must equal the single-launch ones bit for bit, for the forward (bias + dropout) and the dX layouts."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    x, W = bf(randn((M, K), dev, 150)), bf(randn((N, K), dev, 151, 0.1))
+    bias = randn((N,), dev, 152)
+    dy, W2 = bf(randn((M, K), dev, 153)), bf(randn((K, N), dev, 154, 0.1))
+    drop = (0.1, 5, 6)
+    outs = {}
+    for mode in (0, 1):
+        _cabi.set_option("gemm_half_tail", mode)
+        try:
+            outs[mode] = (vf.gemm(x, W, M=M, N=N, K=K, bias=bias, dropout=drop),
+                          vf.gemm(x, W, M=M, N=N, K=K),
+                          vf.gemm(dy, W2, M=M, N=N, K=K, b_trans=True))
+        finally:
+            _cabi.set_option("gemm_half_tail", 1)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert rel(outs[1][1], x.float() @ W.float().t()) < 4e-3
+    assert rel(outs[1][2], dy.float() @ W2.float()) < 4e-3

@@ -21,12 +21,14 @@ def main():
     ap.add_argument("--M", type=int, default=50432)
     args = ap.parse_args()
     cores = [c for c in args.cores.split(",")]  # "5" or "5s8" / "5s10": ping-pong core with an 8- / 10-slot ring
-    def select(c):  # "5", "5s10" (10-slot ring), "5b0" (always 256 workgroups)
-        core, _, bal = c.partition("b")
+    def select(c):  # "5", "5s10" (10-slot ring), "5b0" (always 256 workgroups), "5h0" (no half-tile tail launch)
+        core, _, half = c.partition("h")
+        core, _, bal = core.partition("b")
         core, _, slots = core.partition("s")
         _cabi.set_option("gemm_core", int(core))
         _cabi.set_option("gemm_pp_slots", int(slots) if slots else 8)
         _cabi.set_option("gemm_balance_wgs", int(bal) if bal else 1)
+        _cabi.set_option("gemm_half_tail", int(half) if half else 1)
     dev = torch.device("cuda:0")
     M, D, F = args.M, 768, 3072
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -73,6 +75,7 @@ def main():
     _cabi.set_option("gemm_core", 1)
     _cabi.set_option("gemm_pp_slots", 8)
     _cabi.set_option("gemm_balance_wgs", 1)
+    _cabi.set_option("gemm_half_tail", 1)
     tot = {c: 0.0 for c in cores}
     print(f"{'case':48s} " + " ".join(f"core{c}: us / TF".rjust(20) for c in cores))
     for name, (fn, fl) in cases.items():

@@ -48,6 +48,8 @@ struct Gemm2Args {
   int debug;  // diagnostics only (vit_set_option "gemm_debug"): 1 = no DMA after the prologue, 2 = no MFMA
   int lin_split;  // ping-pong kernel, split-K with one tile per workgroup: 1-D grid of tiles x splits, XCD-contiguous
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
+  int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
+  int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
@@ -333,8 +335,8 @@ static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hi
 //   6 = plain -> bf16                   dX = dY W
 //   7 = plain -> f32 (C or split-K slab)  dW = dY^T X
 // Same per-wave LDS transpose as tile_epilogue on the way in; on the way out a lane owns 16 bytes of output.
-template <int FAST>
-__device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
+template <int FAST, int NI>
+__device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
                                             int lane) {
   const int l15 = lane & 15, lg = lane >> 4;
   if (FAST == 7) {
@@ -343,7 +345,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
     const long ldc = p.splits > 1 ? (long)p.N : p.ldc;
     const int n = n0 + l15 * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         *(f32x4*)(scr + l15 * 256 + (((j * 4 + lg) ^ l15) << 4)) = acc[i][j];
@@ -370,7 +372,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[8][4], char* scr, const
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // column sums of the stored (bf16-rounded) values
   u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NI; ++i) {
     if (FAST == 5 && (i & 3) == 0) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   const int wr = wave >> 2, wc = wave & 3, grp = wr;
   const int l15 = lane & 15, lg = lane >> 4;
 
-  const int ntile = p.tiles_m * p.tiles_n;
+  const int ntile = p.tile_limit > 0 ? p.tile_limit : p.tiles_m * p.tiles_n;
   int split = blockIdx.y, bx = blockIdx.x;
   if (p.lin_split) {
     // split-K (dW = dY^T X: K = all tokens, a few dozen output tiles): one (tile, K-slice) per workgroup on a 1-D grid.
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
       ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
       char* scr = (NSLOT == 8) ? smem + 8 * HALF + wave * SCR : slot_ptr(wave < 4 ? XB1 : XA1) + (wave & 3) * SCR;
-      if constexpr (EPI >= 3) pp_epilogue<EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
+      if constexpr (EPI >= 3) pp_epilogue<EPI, 8>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       else tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
       relaxed = true;
@@ -742,6 +744,184 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #undef PP_STAGE_X
 }
 
+// ------------------------------------------------------------------------------------------------ half-tile tail kernel
+// The tiles of a partial last round (591 tiles = 2 rounds of 256 + 79) would keep 79 workgroups busy for a whole tile-time
+// while 177 CUs idle.  This kernel runs them as 2 x 79 HALF tiles instead: workgroup u takes tile tail_first + u/2 and, in
+// each wave row, the 64-row half h = u & 1 -- every wave computes a 64 x 64 block, the workgroup 128 rows x 256 columns.
+// Same ping-pong structure with TWO phases per K-tile, P1 = (A_h, B0), P2 = (A_h, B1), three half-tiles per K-tile in the
+// stream order A B0 B1, each issued three phases before its first read (odd phases issue one half-tile, even phases
+// two), 8-slot ring (slot = stream index % 8: restaged >= 2 phases after the last read), vmcnt(6) = three half-tiles in
+// flight at every wait.  A separate code object on purpose: the main kernel's register allocation is untouched.
+template <int A_T, int B_T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int HALF = 128 * BK * 2, NSLOT = 8;
+  constexpr int SCR = 4096, CW = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, grp = wr;
+  const int l15 = lane & 15, lg = lane >> 4;
+  // XCD-contiguous unit order: the two halves of a tile (same B half-tiles at the same time) land on one XCD
+  const int total = 2 * p.tail_n, lin = blockIdx.x;
+  const int q_ = total >> 3, r_ = total & 7, xcd = lin & 7, within = lin >> 3;
+  const int unit = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + within;
+  const int t = p.tail_first + (unit >> 1), h = unit & 1;
+  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const int nk = p.K / BK;
+
+  int offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (A_T == 0) {
+      const int rimg = i * 64 + wave * 8 + (lane >> 3);
+      offA[i] = (i * 128 + wave * 8 + (lane >> 3)) * (int)p.lda + (((lane & 7) ^ ((rimg >> 1) & 7)) << 3);
+    } else {
+      const int k = i * 32 + wave * 4 + (lane >> 4);
+      const int c16 = (lane & 15) ^ (tr_swz2(k) >> 1);
+      offA[i] = k * (int)p.lda + (c16 >> 3) * 128 + ((c16 & 7) << 3);
+    }
+    if (B_T == 0) {
+      const int rimg = i * 64 + wave * 8 + (lane >> 3);
+      offB[i] = ((rimg >> 5) * 64 + (rimg & 31)) * (int)p.ldb + (((lane & 7) ^ ((rimg >> 1) & 7)) << 3);
+    } else {
+      const int k = i * 32 + wave * 4 + (lane >> 4);
+      const int c16 = (lane & 15) ^ (tr_swz2(k) >> 1);
+      offB[i] = k * (int)p.ldb + (c16 >> 2) * 64 + ((c16 & 3) << 3);
+    }
+  }
+  const long halfA = ((A_T == 0) ? 64 * p.lda : 64) * h, halfB = (B_T == 0) ? 32 * p.ldb : 32;
+  const char* a_base = (A_T == 0) ? p.A + ((long)tm * BM * p.lda) * 2 : p.A + ((long)tm * BM) * 2;
+  const char* b_base = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb) * 2 : p.B + ((long)tn * BN) * 2;
+  const long kstepA = (A_T == 0) ? BK : (long)BK * p.lda, kstepB = (B_T == 0) ? BK : (long)BK * p.ldb;  // elements per K-tile
+
+  int islot = 0;
+  auto issue_half = [&](const char* base, long off_el, const int (&off)[2]) {
+    char* dst = smem + islot * HALF + wave * 1024;
+    islot = (islot + 1) & (NSLOT - 1);
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
+  };
+  auto issue_A = [&](int kt) { issue_half(a_base, kt * kstepA + halfA, offA); };
+  auto issue_B = [&](int kt, int hb) { issue_half(b_base, kt * kstepB + hb * halfB, offB); };
+
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int tr_f = (tq | ((lg & 1) << 2)) << 2;
+  int kc_off[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) kc_off[s] = l15 * 128 + (((s * 4 + lg) ^ (l15 >> 1)) << 4);
+  auto read_frag = [&](const char* img, int trans, int base16, int s) -> bf16x8 {
+    if (!trans) {
+      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off[s]);
+    } else {
+      const char* pa = img + (s * 32 + lg * 8 + tq) * 256 + ((((base16 >> 2) + tp) ^ tr_f) << 3);
+      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
+      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * 256));
+      return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bq[2][2];
+
+#define HT_MFMA(HB)                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                 \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+          acc[i_][HB * 2 + j_] =                                                                 \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j_][s_], af[i_][s_], acc[i_][HB * 2 + j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();
+
+  // prologue: everything first read in phases 1..3 = A B0 B1 of K-tile 0, A B0 of K-tile 1 (stream indices 0..4)
+  issue_A(0);
+  issue_B(0, 0);
+  issue_B(0, 1);
+  if (1 < nk) {
+    issue_A(1);
+    issue_B(1, 0);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+
+  int rslot = 0;  // slot of A of the current K-tile (stream index 3 kt)
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sA = smem + rslot * HALF;
+    const char* sB0 = smem + ((rslot + 1) & 7) * HALF;
+    const char* sB1 = smem + ((rslot + 2) & 7) * HALF;
+    // P1 = (A, B0); issues B1 of K-tile kt + 1 (first read three phases on)
+#pragma unroll
+    for (int j_ = 0; j_ < 2; ++j_)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) bq[j_][s_] = read_frag(sB0, B_T, wc * 32 + j_ * 16, s_);
+#pragma unroll
+    for (int i_ = 0; i_ < 4; ++i_)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) af[i_][s_] = read_frag(sA, A_T, wr * 64 + i_ * 16, s_);
+    if (kt + 1 < nk) {
+      issue_B(kt + 1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    HT_MFMA(0)
+    // P2 = (A, B1); issues A and B0 of K-tile kt + 2
+#pragma unroll
+    for (int j_ = 0; j_ < 2; ++j_)
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) bq[j_][s_] = read_frag(sB1, B_T, wc * 32 + j_ * 16, s_);
+    if (kt + 2 < nk) {
+      issue_A(kt + 2);
+      issue_B(kt + 2, 0);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    HT_MFMA(1)
+    rslot = (rslot + 3) & 7;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier: everyone is done with the ring
+#undef HT_MFMA
+  char* scr = smem + 8 * HALF + wave * SCR;
+  const int m0 = tm * BM + wr * 128 + h * 64, n0 = tn * BN + wc * 64;
+  if constexpr (EPI >= 3) pp_epilogue<EPI, 4>(acc, scr, p, m0, n0, 0, lane);
+  else tile_epilogue<4, 4, CW, EPI>(acc, scr, p, m0, n0, 0, lane);
+}
+
+template <int AT, int BT, int EPI>
+static int launch_half(const Gemm2Args& a, hipStream_t st) {
+  constexpr int smem = 160 * 1024;
+  static bool attr_done = false;
+  auto fn = gemm3h_kernel<AT, BT, EPI>;
+  if (!attr_done) {
+    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(2 * a.tail_n), dim3(512), smem, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+// the epilogue kinds whose GEMMs have N = hidden outputs (the tile counts that leave partial rounds): Y = X W^T with
+// bias / dropout (3) and dX = dY W (6); everything else keeps the single launch
+static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
+  if (epi == 3) return launch_half<0, 0, 3>(a, st);
+  return launch_half<0, 1, 6>(a, st);
+}
+
+int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
 int g_pp_slots = 8;  // vit_set_option("gemm_pp_slots"): half-tile slots of the ping-pong ring, 8 (default) or 10
 template <int AT, int BT, int EPI, int NSLOT>
@@ -844,12 +1024,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.slab = (float*)ws;
   }
   a.nblk = std::min(ntile, slots);
-  if (cfg == 5 && g_balance_wgs && ntile > slots) {
-    // multi-round persistent walk: the makespan is ceil(ntile / slots) tile-times whatever the workgroup count, so launch
-    // just enough workgroups for that many rounds (591 tiles -> 197 workgroups x 3 instead of 256 of which 177 idle a
-    // third of the time): the idle CUs' power budget goes to the busy ones' clock, and L2 / fabric see less contention
-    a.nblk = cdiv(ntile, cdiv(ntile, slots));
-  }
+  a.tile_limit = 0; a.tail_first = 0; a.tail_n = 0;
   a.bias = d->bias;
   a.aux_in = (const short*)d->aux_in; a.aux_out = (short*)d->aux_out; a.ldaux = d->ldaux;
   a.residual = d->residual; a.ldres = d->ldres;
@@ -880,6 +1055,24 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
              splits == 1) epi5 = 6;
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_F32 && d->a_trans && d->b_trans) epi5 = 7;
   }
+  // the tiles of a partial last round go to the half-tile kernel (two workgroups per tile) when the epilogue is one of
+  // the two kinds instantiated for it and nothing else rides on the launch
+  int half_tail = 0;
+  if (cfg == 5 && g_half_tail && (epi5 == 3 || epi5 == 6) && splits == 1 && ntile > slots && !d->colsum_out) {
+    const int tail = ntile % slots;
+    if (tail > 0 && 2 * tail <= slots && d->K / 64 >= 4) half_tail = tail;
+  }
+  if (cfg == 5 && g_balance_wgs && splits == 1 && ntile - half_tail > slots) {
+    // multi-round persistent walk: the makespan is ceil(tiles / slots) tile-times whatever the workgroup count, so launch
+    // just enough workgroups for that many rounds: the idle CUs' power budget goes to the busy ones' clock
+    a.nblk = cdiv(ntile - half_tail, cdiv(ntile - half_tail, slots));
+    grid = dim3(a.nblk, splits);
+  }
+  if (half_tail) {
+    a.tile_limit = ntile - half_tail;
+    a.tail_first = ntile - half_tail;
+    a.tail_n = half_tail;
+  }
   if (d->colsum_out && cfg == 5 && (epi5 == 3 || epi5 == 5 || epi5 == 6)) {
     size_t wsb = 0;
     void* ws = ctx_workspace(h, &wsb);
@@ -895,7 +1088,10 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   int r;
   if (cfg == 2) r = launch_cfg<256, 256, 64, 2, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   else if (cfg == 3) r = launch_cfg<256, 128, 64, 3, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else if (cfg == 5) r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
+  else if (cfg == 5) {
+    r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
+    if (r == VIT_OK && half_tail) r = launch_half_cfg(a, epi5, st);
+  }
   else if (cfg == 6) r = launch_cfg<256, 128, 32, 3, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
   else r = launch_cfg<256, 256, 32, 4, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
   if (r == VIT_OK && a.colsum_part) {
