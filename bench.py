@@ -137,14 +137,26 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         log(f"timing {args.steps} steps")
-    if not args.no_kernel_timing:
-        timing_on[0] = True
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = trainer.training_step(module, batch, i)
     barrier()
     dt = time.perf_counter() - t0
+    # The per-GEMM HIP-event brackets (two event records around each of ~170 vit_gemm calls per step) cost 2-4 % of a
+    # step, so `value` comes from the clean region above and the kernel-level roofline from an instrumented repetition
+    # of the same steps right after it (same state, same inputs; `roofline.instrumented_ms_per_step` says what they took).
+    dt_inst, n_inst = None, 0
+    if not args.no_kernel_timing:
+        n_inst = min(args.steps, 20)
+        timing_on[0] = True
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n_inst):
+            trainer.training_step(module, batch, i)
+        barrier()
+        dt_inst = time.perf_counter() - t1
+        timing_on[0] = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -189,9 +201,10 @@ def main():
             "bound": "mfma", "kernel": var, "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12,
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
             "flop_per_launch": fl / n, "mean_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
-            "share_of_step_time": round(ms / (dt * 1e3), 3),
+            "share_of_step_time": round(ms / (dt_inst * 1e3), 3),
             "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
-            "all_gemm_share_of_step_time": round(gemm_ms / (dt * 1e3), 3),
+            "all_gemm_share_of_step_time": round(gemm_ms / (dt_inst * 1e3), 3),
+            "instrumented_steps": n_inst, "instrumented_ms_per_step": round(dt_inst / n_inst * 1e3, 3),
             "step_tflops": round(value / world * flop_img / 1e12, 2),
             "step_frac": round(value / world * flop_img / PEAK_BF16_DENSE, 4),
         }
