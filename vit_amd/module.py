@@ -175,13 +175,10 @@ class ViTLModule(BaseLightningModule):
         if self.noise_level > 0:
             # vit.py:86-88; on the device through vit_add_noise (no arithmetic of the path runs in torch), one fresh
             # seed per step drawn from torch's seeded CPU generator so that seed_everything(42) fixes the whole run
-            if flux.is_cuda:
-                from . import functional as vf
+            from . import functional as vf
 
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-                noisy = vf.add_noise(flux.contiguous().float(), error.contiguous().float(), self.noise_level, seed)
-            else:
-                noisy = flux + torch.randn_like(flux) * error * self.noise_level
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            noisy = vf.add_noise(flux.contiguous().float(), error.contiguous().float(), self.noise_level, seed)  # raises off-GPU
             loss = self(noisy, labels, loss_only=True)
         else:
             loss = self(flux, labels, loss_only=True)
