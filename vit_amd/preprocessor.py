@@ -85,12 +85,16 @@ class _LinearFn(torch.autograd.Function):
 
         B, L = x.shape
         r = weight.shape[0]
-        xo, wo = x.contiguous().to(op_dtype), weight.contiguous().to(op_dtype)
+        x, weight = x.contiguous(), weight.contiguous()
+        if op_dtype == torch.bfloat16:  # the operand casts go through the library too (vit_cast_f32_bf16)
+            xo, wo = vf.cast_f32_bf16(x), vf.cast_f32_bf16(weight)
+        else:
+            xo, wo = x, weight
         y = vf.gemm(xo, wo, M=B, N=r, K=L, bias=bias, out_dtype=torch.float32)
         ctx.save_for_backward(xo)
         ctx.shape = (B, L, r)
         ctx.has_bias = bias is not None
-        ctx.need_w = weight.requires_grad
+        ctx.need_w = bool(ctx.needs_input_grad[1])
         return y
 
     @staticmethod
@@ -101,7 +105,9 @@ class _LinearFn(torch.autograd.Function):
         B, L, r = ctx.shape
         dw = db = None
         if ctx.need_w:
-            dyo = dy.contiguous().to(xo.dtype)
+            dyo = dy.contiguous()
+            if xo.dtype == torch.bfloat16:
+                dyo = vf.cast_f32_bf16(dyo.float())
             dw = vf.gemm(dyo, xo, M=r, N=L, K=B, a_trans=True, b_trans=True, out_dtype=torch.float32, split_k=-1)
             if ctx.has_bias:
                 db = vf.colsum(dy.contiguous().float())
