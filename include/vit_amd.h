@@ -53,7 +53,8 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                workgroups per CU.
  *   "attn_split": workgroups per (batch, head) in the resident attention kernels (T <= 256), default 2.
  *   "gemm_half_tail": 1 (default) = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
- *                and plain dX epilogues) run in a second launch as half tiles, two workgroups per tile; 0 = one launch.
+ *                and plain dX epilogues; 2 = the GELU epilogue too) run in a second launch as half tiles, two workgroups per
+ *                tile; 0 = one launch.
  *   "gemm_balance_wgs": 1 (default) = a multi-round ping-pong GEMM launches ceil(tiles / rounds) workgroups instead of 256
  *                (same makespan in tile-times, idle CUs instead of CUs that idle for the last round); 0 = always 256.
  *   "gemm_pp_slots": 8 (default) or 10 half-tile slots in the ping-pong core's LDS ring: 64 or 96 KiB of operand

@@ -914,7 +914,8 @@ static int launch_half(const Gemm2Args& a, hipStream_t st) {
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
-// instantiated for Y = X W^T with bias / dropout (3) or GELU (4) and for dX = dY W (6); everything else keeps the single launch
+// instantiated for Y = X W^T with bias / dropout (3) or GELU (4) and for dX = dY W (6); the GELU kind only on request
+// (gemm_half_tail = 2): at 9.2 rounds the 0.2 of a round it could save is less than the second launch costs (measured)
 static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
   if (epi == 3) return launch_half<0, 0, 3>(a, st);
   if (epi == 4) return launch_half<0, 0, 4>(a, st);
@@ -1058,7 +1059,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   // the tiles of a partial last round go to the half-tile kernel (two workgroups per tile) when the epilogue is one of
   // the kinds instantiated for it and nothing else rides on the launch
   int half_tail = 0;
-  if (cfg == 5 && g_half_tail && (epi5 == 3 || epi5 == 4 || epi5 == 6) && splits == 1 && ntile > slots && !d->colsum_out) {
+  if (cfg == 5 && g_half_tail && (epi5 == 3 || epi5 == 6 || (epi5 == 4 && g_half_tail > 1)) && splits == 1 && ntile > slots && !d->colsum_out) {
     const int tail = ntile % slots;
     if (tail > 0 && 2 * tail <= slots && d->K / 64 >= 4) half_tail = tail;
   }
