@@ -52,6 +52,8 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                segment, ring of 8 half-tiles, 4 in flight), 6 the 4-wave 256x128xBK32 (3 stages) geometry with two
  *                workgroups per CU.
  *   "attn_split": workgroups per (batch, head) in the resident attention kernels (T <= 256), default 2.
+ *   "attn_res_max_t": longest sequence the resident attention kernels take (default 592 = what fits the LDS at head_dim
+ *                64); longer ones, or everything with 0, go to the tiled kernels.
  *   "gemm_half_tail": 1 (default) = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
  *                and plain dX epilogues; 2 = the GELU epilogue too) run in a second launch as half tiles, two workgroups per
  *                tile; 0 = one launch.

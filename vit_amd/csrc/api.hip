@@ -14,7 +14,7 @@ struct vit_ctx {
 namespace vit {
 
 extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail;  // gemm2.hip
-extern int g_attn_split;                           // attention.hip
+extern int g_attn_split, g_attn_res_max_t;         // attention.hip
 
 static thread_local char g_err[512] = "";
 thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
@@ -77,6 +77,10 @@ int vit_set_option(const char* name, int value) {
   if (strcmp(name, "attn_split") == 0) {
     if (value < 1 || value > 8) return VIT_ERR_ARG;
     vit::g_attn_split = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "attn_res_max_t") == 0) {
+    vit::g_attn_res_max_t = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_half_tail") == 0) {

@@ -783,12 +783,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   const short* kb_ = qb + p.H * dh;
   const short* vb = kb_ + p.H * dh;
   const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  // only the 16-row blocks that hold queries are staged (like K / V in the other two kernels): T = 577 -> 592 rows,
+  // 2 x 74 KiB + 4.6 KiB of row statistics fit the CU's 160 KiB
+  const int rows_alloc = (T + 15) & ~15;
   char* Qimg = smem;
-  char* Oimg = smem + ntl * TILE;
-  float* lse_s = (float*)(smem + 2 * ntl * TILE);
-  float* del_s = lse_s + ntl * RT;
-  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, ntl * RT, tid, blockDim.x);
-  for (int i = tid; i < ntl * RT; i += blockDim.x) {
+  char* Oimg = smem + rows_alloc * (DH * 2);
+  float* lse_s = (float*)(smem + 2 * rows_alloc * (DH * 2));
+  float* del_s = lse_s + rows_alloc;
+  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, rows_alloc, tid, blockDim.x);
+  for (int i = tid; i < rows_alloc; i += blockDim.x) {
     lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
     del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
   }
@@ -878,8 +881,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
       }
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        const bf16x8 otf = frag_cols<DH>(Ot, u * 32, u * 32 + 16, dt * 16, l15, lg);
-        const bf16x8 qtf = frag_cols<DH>(Qt, u * 32, u * 32 + 16, dt * 16, l15, lg);
+        const int rb1 = (qb0 + u * 32 + 16 < T) ? u * 32 + 16 : u * 32;  // an un-staged block: its P and dS are 0
+        const bf16x8 otf = frag_cols<DH>(Ot, u * 32, rb1, dt * 16, l15, lg);
+        const bf16x8 qtf = frag_cols<DH>(Qt, u * 32, rb1, dt * 16, l15, lg);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
           dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
@@ -925,12 +929,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   }
 }
 
-constexpr int RES_MAX_T = 256, RES_MAX_DH = 64, RES_RQ = 2;
+// resident kernels: a (batch, head)'s whole K/V (or Q/dO) in the LDS -- at head_dim 64 up to T = 592 rows (2 x 74 KiB; the
+// backward adds 4.6 KiB of row statistics): ViT-L/16 384^2 (T = 577) fits, one workgroup per CU, three workgroups of 7
+// waves per head
+constexpr int RES_MAX_T = 592, RES_MAX_DH = 64, RES_RQ = 2;
+int g_attn_res_max_t = RES_MAX_T;  // vit_set_option("attn_res_max_t"): larger T goes to the tiled kernels
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
+
+static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + two f32 rows of statistics
+  const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
+  return 2 * rows * dhp * 2 + 2 * rows * 4 <= 160 * 1024;
+}
 
 static void res_geometry(int T, int* nsplit, int* wpw) {
   const int nq = cdiv(T, 16), nw = cdiv(nq, RES_RQ);
-  *nsplit = std::max(1, std::min(g_attn_split, nw));
+  *nsplit = std::max(1, std::min(std::max(g_attn_split, cdiv(nw, 8)), nw));  // at most 8 waves per workgroup
   *wpw = cdiv(nw, *nsplit);
   *nsplit = cdiv(nw, *wpw);
 }
@@ -1168,7 +1181,7 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
   a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
-  if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
+  if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     const size_t ntl = cdiv(T, RT);
     DISPATCH_RES(attn_fwd_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), (hipStream_t)stream, rc);
     return rc;
@@ -1195,7 +1208,7 @@ int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, con
                              float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream) {
   VIT_CHECK(dqkv_colsum, VIT_ERR_ARG, "vit_attention_bwd_colsum: null dqkv_colsum");
   const int D3 = 3 * H * dh;
-  if (io_dtype == VIT_BF16 && T <= RES_MAX_T && dh <= RES_MAX_DH && (dh % 4) == 0) {
+  if (io_dtype == VIT_BF16 && T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && (dh % 4) == 0 && res_fits(T, dh)) {
     int nsplit, wpw;
     res_geometry(T, &nsplit, &wpw);
     size_t wsb = 0;
@@ -1239,11 +1252,11 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
   a.csum_part = colsum_part;
-  if (T <= RES_MAX_T && dh <= RES_MAX_DH) {
+  if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     const size_t ntl = cdiv(T, RT);
     DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
-    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * ntl * RT * DH_ * 2 + 2 * ntl * RT * 4), st, rc);
+    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 2 * (size_t)((T + 15) & ~15) * 4), st, rc);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
