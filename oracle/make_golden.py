@@ -322,6 +322,14 @@ def make_prep():
         out["y_zca_r16_s2"] = LinearPreprocessor(P, bias=bias, freeze=True)(x).numpy()
         Pp = torch.from_numpy(out["pca_r16"])
         out["y_pca_r16"] = LinearPreprocessor(Pp, bias=-mean @ Pp.t(), freeze=True)(x).numpy()
+    # warmup.preprocessor: attention -- on 2-D spectra the module is its query projection (attention.py:81-84)
+    from src.models.attention import PrefilledAttention
+    for key, kw in {"attn_r16": dict(r=16, scale_by_eigvals=True), "attn_r24_noscale": dict(r=24, scale_by_eigvals=False)}.items():
+        torch.manual_seed(3)
+        m = PrefilledAttention(input_dim=Dm, eigvecs=vec, eigvals=lam, eps=1e-5, **kw)
+        out[key + "_wq"] = m.q_lin.weight.detach().numpy()
+        with torch.no_grad():
+            out[key + "_y"] = m(x).numpy()
     path = os.path.join(ROOT, "tests", "golden", "prep.npz")
     np.savez_compressed(path, **out)
     print(f"[prep] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")

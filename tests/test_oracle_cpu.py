@@ -232,3 +232,18 @@ def test_spec_dataset_contract():
     assert cl.labels.dtype == torch.int64 and torch.equal(cl.labels, (logg > 2.5).long())
     batches = list(SpecLoader(tr, 16, shuffle=True, seed=1))
     assert sum(b[0].shape[0] for b in batches) == 40 and batches[0][0].shape == (16, 64)
+
+
+def test_prefilled_attention_weights_match_reference():
+    """vit_amd.preprocessor.PrefilledAttention: prefilled query weights against the reference module's (prep.npz), and the
+    state_dict surface (q_lin / k_lin / v_lin .weight; set_qk_trainable)."""
+    from vit_amd.preprocessor import PrefilledAttention
+
+    g = np.load(os.path.join(GOLD, "prep.npz"))
+    vec, lam = torch.from_numpy(g["eigvecs"]), torch.from_numpy(g["eigvals"])
+    a = PrefilledAttention(48, vec, lam, r=16, scale_by_eigvals=True, eps=1e-5)
+    b = PrefilledAttention(48, vec, lam, r=24, scale_by_eigvals=False)
+    assert rel(a.q_lin.weight.detach(), g["attn_r16_wq"]) < 1e-6 and rel(b.q_lin.weight.detach(), g["attn_r24_noscale_wq"]) < 1e-7
+    assert sorted(a.state_dict()) == ["k_lin.weight", "q_lin.weight", "v_lin.weight"] and a.out_features == 16
+    a.set_qk_trainable(False)
+    assert [n for n, p in a.named_parameters() if p.requires_grad] == ["v_lin.weight"]

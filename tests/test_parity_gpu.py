@@ -504,3 +504,16 @@ def test_trainable_preprocessor_gradients_and_step(dev, stride):
     model.set_preprocessor_trainable(False)
     assert [n for n, _ in model.named_parameters() if n.startswith("preprocessor")] == []
     model(x.to(dev), labels=labels.to(dev)).loss.backward()
+
+
+def test_prefilled_attention_forward_matches_reference(dev):
+    """`warmup.preprocessor: attention` on 2-D spectra = the prefilled query projection (attention.py:81-84): one vit_gemm,
+    against the reference module's outputs (prep.npz)."""
+    from vit_amd.preprocessor import PrefilledAttention
+
+    g = np.load(os.path.join(GOLD, "prep.npz"))
+    vec, lam = torch.from_numpy(g["eigvecs"]), torch.from_numpy(g["eigvals"])
+    x = torch.from_numpy(g["x"]).to(dev)
+    for key, kw in {"attn_r16": dict(r=16, scale_by_eigvals=True), "attn_r24_noscale": dict(r=24, scale_by_eigvals=False)}.items():
+        m = PrefilledAttention(48, vec, lam, eps=1e-5, **kw).to(dev)
+        assert rel(m(x), torch.from_numpy(g[key + "_y"])) < 2e-5

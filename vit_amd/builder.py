@@ -1,11 +1,11 @@
 """`get_model(config)`: mirrors the reference's model factory (src/models/builder.py:136-197): the vanilla ViT, or a ViT behind
 a linear input preprocessor (ZCA whitening / PCA projection built from covariance statistics on disk; `warmup:` section of
-the config).  The prefilled-attention preprocessor (`warmup.preprocessor: attention`, src/models/attention.py) is not built.
+the config), or behind the prefilled-attention preprocessor in the 2-D form the ViT path uses (its query projection).
 """
 from __future__ import annotations
 
 from .config import get_vit_config
-from .preprocessor import LinearPreprocessor, compute_pca_matrix, compute_zca_matrix, load_cov_stats
+from .preprocessor import LinearPreprocessor, PrefilledAttention, compute_pca_matrix, compute_zca_matrix, load_cov_stats
 from .specvit import MyViT
 
 __all__ = ["get_model", "get_vit_config"]
@@ -33,9 +33,13 @@ def _build_preprocessor(preproc_type: str, warmup_cfg: dict, stats: dict, initia
         P = compute_pca_matrix(eigvecs, r=r)
         rank = f"PCA{r}" if r is not None else "PCA"
         prefix = f"{rank}_fz{fz}" + ("" if use_bias else "_nobias")
-    elif preproc_type == "attention":
-        raise NotImplementedError("warmup.preprocessor='attention' (PrefilledAttention, src/models/attention.py) is not part "
-                                  "of the MI355X path")
+    elif preproc_type == "attention":  # builder.py:110-129
+        eigvals = stats.get("eigvals", None)
+        scale = warmup_cfg.get("scale_by_eigvals", True)
+        pre = PrefilledAttention(input_dim=int(eigvecs.shape[0]), eigvecs=eigvecs, eigvals=eigvals, r=r,
+                                 scale_by_eigvals=scale, eps=warmup_cfg.get("eps", 1e-5))
+        prefix = f"Attn{r if r else 'Full'}" + ("_scaled" if scale and eigvals is not None else "") + f"_fz{fz}"
+        return pre, (r if r is not None else int(eigvecs.shape[0])), prefix
     else:
         raise ValueError(f"Unknown preprocessor type: '{preproc_type}'")  # builder.py:131
     bias = (-mean @ P.t()) if (use_bias and mean is not None) else None

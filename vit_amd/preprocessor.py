@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-__all__ = ["LinearPreprocessor", "compute_zca_matrix", "compute_pca_matrix", "load_cov_stats"]
+__all__ = ["LinearPreprocessor", "PrefilledAttention", "compute_zca_matrix", "compute_pca_matrix", "load_cov_stats"]
 
 
 def _shrunk(eigvals: torch.Tensor, shrinkage: float) -> torch.Tensor:
@@ -167,3 +167,60 @@ class LinearPreprocessor(nn.Module):
 
             raise VitError("LinearPreprocessor: the input must live on the GPU (there is no CPU path)")
         return _LinearFn.apply(x.to(torch.float32), self.linear.weight, self.linear.bias, self.op_dtype)
+
+
+class PrefilledAttention(nn.Module):
+    """`warmup.preprocessor: attention` (src/models/attention.py:12-121): query / key projections prefilled with the
+    (optionally 1/sqrt(eigenvalue)-scaled) leading eigenvectors.  The ViT hands it 2-D spectra, for which the reference's
+    forward IS the query projection (attention.py:81-84: `if x.dim() == 2: return self.q_lin(x)`) -- one vit_gemm here;
+    the key / value projections exist only as parameters (same state_dict keys: q_lin / k_lin / v_lin .weight), and the 3-D
+    self-attention branch, which the ViT path never reaches, is not built."""
+
+    class _Lin(nn.Module):
+        def __init__(self, weight):
+            super().__init__()
+            self.weight = nn.Parameter(weight)
+
+    def __init__(self, input_dim: int, eigvecs: torch.Tensor, eigvals: Optional[torch.Tensor] = None, r: Optional[int] = None,
+                 low_rank: Optional[bool] = None, scale_by_eigvals: bool = True, eps: float = 1e-5) -> None:
+        super().__init__()
+        import math
+
+        self.input_dim = input_dim
+        self.r = r if r is not None else eigvecs.shape[1]
+        self.low_rank = low_rank if low_rank is not None else (self.r < input_dim)
+        self.scale_by_eigvals = scale_by_eigvals and eigvals is not None
+        basis = eigvecs[:, : self.r].t().contiguous().to(torch.float32)            # [r, D]
+        if self.scale_by_eigvals:
+            basis = basis * torch.rsqrt(eigvals[: self.r].to(torch.float32) + eps).unsqueeze(1)
+        if self.low_rank:
+            wq = basis.clone()
+        else:
+            wq = torch.zeros(input_dim, input_dim)
+            wq[: basis.shape[0], :] = basis
+        self.q_lin = PrefilledAttention._Lin(wq)
+        self.k_lin = PrefilledAttention._Lin(wq.clone())
+        wv = torch.empty(input_dim, input_dim)
+        nn.init.kaiming_uniform_(wv, a=math.sqrt(5))
+        self.v_lin = PrefilledAttention._Lin(wv)
+        self.op_dtype = torch.float32
+
+    @property
+    def out_features(self) -> int:
+        return int(self.q_lin.weight.shape[0])
+
+    def set_qk_trainable(self, trainable: bool = True) -> None:  # attention.py:98-103
+        self.q_lin.weight.requires_grad = trainable
+        self.k_lin.weight.requires_grad = trainable
+
+    def set_precision(self, precision) -> None:
+        self.op_dtype = torch.bfloat16 if str(precision).lower() in ("bf16-mixed", "bf16", "16-mixed") else torch.float32
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 2:
+            raise NotImplementedError("PrefilledAttention: only the 2-D (spectra) form the ViT path uses is built")
+        if not x.is_cuda:
+            from ._cabi import VitError
+
+            raise VitError("PrefilledAttention: the input must live on the GPU (there is no CPU path)")
+        return _LinearFn.apply(x.to(torch.float32), self.q_lin.weight, None, self.op_dtype)
