@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X ViT training hot path (BASELINE.json metric: images/sec of a ViT-B/16 224^2 bf16 train step).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment: this process IS a rank), or from a plain shell, where this process only
+launches N fresh rank processes of itself (it never touches the GPU), waits for them and exits with their status.
 
 A "step" is one full optimisation step of the reference's `training_step` path on one synthetic batch that is already
 resident in HBM: forward (dropout on) -> backward -> [RCCL gradient all-reduce, overlapped] -> global-norm clip 0.5 ->
@@ -42,12 +46,37 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def ms_per_step_of(dt, steps):
+    return dt / steps * 1e3
+
+
 def train_flop_per_image(L, P, D, layers, F):
     """2*3*[N*P*D + layers*(3TD^2 + 2T^2 D + TD^2 + 2TDF) + D^2 + D]."""
     N = L // P
     T = N + 1
     macs = N * P * D + layers * (3 * T * D * D + 2 * T * T * D + T * D * D + 2 * T * D * F) + D * D + D
     return 6.0 * macs
+
+
+def launch_check(n_expected: int):
+    """CPU-only rehearsal of the rank plumbing of `bench.py --gpus N` (tests/test_launch_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+
+    from vit_amd import ddp as ddp_mod
+
+    rank, local, world = ddp_mod.init_distributed(backend="gloo")
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": n_expected, "world": world, "rank_sum": float(t),
+                          "backend": dist.get_backend() if world > 1 else None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if world != n_expected:
+        raise SystemExit(f"--gpus {n_expected} but WORLD_SIZE={world}")
 
 
 def main():
@@ -61,7 +90,18 @@ def main():
                     help="bf16-mixed = the BASELINE.json metric; 32 = the fp32-class mode (x3 GEMMs), for the record only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
+    ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rank plumbing only (no GPU): every rank joins a gloo group, rank 0 prints {world, sum of ranks}")
     args = ap.parse_args()
+
+    from vit_amd.launch import launch_ranks, under_launcher  # imports neither torch nor HIP
+
+    if args.gpus > 1 and not under_launcher():
+        # plain shell: this process only starts the N rank processes and never touches the GPU
+        sys.exit(launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.launch_check:
+        return launch_check(args.gpus)
 
     import torch
 
@@ -162,6 +202,43 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
     final_loss = float(loss.detach())
+
+    # ---- N > 1: what the gradient exchange costs.  (a) the same steps with the exchange switched off (replicas drift
+    # apart, which no longer matters: `value` is already taken), (b) the bare all-reduce of the flat gradient buffer in
+    # the step's own buckets with nothing else on the GPU -> algorithm / bus bandwidth over xGMI.
+    comm = None
+    if world > 1:
+        dist = torch.distributed
+        eng = module.model.engine
+        red = trainer.reducer
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "exchange": red.mode,
+                "collectives_per_step": red.calls_per_step, "bytes_per_step": red.bytes_per_step}
+        if not args.no_comm_probe:
+            n_probe = min(args.steps, 10)
+            trainer.reducer, eng.grad_ready_cb = None, None
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(n_probe):
+                trainer.training_step(module, batch, i)
+            barrier()
+            dt_off = time.perf_counter() - t2
+            trainer.reducer, eng.grad_ready_cb = red, red.bucket_ready
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(n_probe):
+                for lo, hi in eng.layout.buckets():
+                    red.bucket_ready(lo, hi)
+                red.finish()
+            barrier()
+            dt_ar = time.perf_counter() - t3
+            t = torch.tensor([dt_off, dt_ar], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_off, dt_ar = float(t[0]), float(t[1])
+            alg = red.bytes_per_step / (dt_ar / n_probe) / 1e9
+            comm.update({"ms_per_step_exchange_off": round(dt_off / n_probe * 1e3, 3),
+                         "exposed_exchange_ms": round(ms_per_step_of(dt, args.steps) - dt_off / n_probe * 1e3, 3),
+                         "bare_allreduce_ms": round(dt_ar / n_probe * 1e3, 3), "algbw_GBps": round(alg, 1),
+                         "busbw_GBps": round(alg * 2 * (world - 1) / world, 1), "probe_steps": n_probe})
     if rank == 0:
         log(f"{args.steps} steps in {dt:.3f} s -> {world * B * args.steps / dt:.1f} images/s, loss {final_loss:.5f}")
 
@@ -188,18 +265,22 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12
         gemm_ms = sum(v[1] for v in agg.values())
         gemm_fl = sum(v[2] for v in agg.values())
-        traffic = None  # HBM bytes per launch of that kernel, from the committed PMC passes (profiles/*pmc_traffic.json)
+        # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 around the process);
+        # it is the figure from the newest committed PMC passes of this same command, and `traffic_source` says which
+        traffic, traffic_source = None, None
         try:
             import glob
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
                 ent = json.load(open(path))["kernels"].get(var)
                 if ent and args.workload == "vit_b16_224" and B == 256:
                     traffic = ent["hbm_bytes_per_launch"]
+                    traffic_source = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc passes of this command, committed; constant, not re-measured here)"
         except Exception:  # noqa: BLE001 - the profile summary is optional evidence, never required to run
             traffic = None
         roofline = {
             "bound": "mfma", "kernel": var, "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE / 1e12,
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_BF16_DENSE, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
             "flop_per_launch": fl / n, "mean_launch_us": round(ms / n * 1e3, 2), "launches_timed": n,
             "share_of_step_time": round(ms / (dt_inst * 1e3), 3),
             "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
@@ -223,7 +304,7 @@ def main():
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
                        "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
                        "final_loss": final_loss},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "comm": comm, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -255,7 +336,7 @@ def run_cpu_baseline(workload, L, P, D, layers, heads):
     t0 = time.perf_counter()
     tr.step(flux, labels)  # warm-up
     log(f"cpu baseline: warm-up step {time.perf_counter() - t0:.1f} s")
-    n = 2
+    n = 3  # 1 warm-up + 3 timed steps
     t0 = time.perf_counter()
     for i in range(n):
         tr.step(flux, labels)

@@ -73,6 +73,10 @@ class GradAllReducer:
         self._pending = []
         self._seen = 0
         self.bytes_reduced = 0
+        self.mode = "allreduce"
+        # what one step puts on the wire (for bench.py's `comm` object)
+        self.calls_per_step = sum(-(-(hi - lo) // max_bucket_elems) for lo, hi in buckets if hi > lo)
+        self.bytes_per_step = 4 * sum(hi - lo for lo, hi in buckets if hi > lo)
 
     def bucket_ready(self, lo: int, hi: int):
         """Engine callback (called on the host right after the kernels that complete grads[lo:hi] were enqueued)."""
