@@ -334,6 +334,143 @@ def make_prep():
     np.savez_compressed(path, **out)
     print(f"[prep] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
+def make_deep(tag, rc, batch, wseed, xseed, steps=2):
+    """C3 / C5 ("too big to commit: pin them by per-tensor checksums/norms + 16 sampled rows").  The reference
+    composition (get_vit_config + HF ViTModel + the reference's SpectraEmbeddings) at the BENCHMARKED depth/width pins the
+    restatement there too; the fixture keeps norms of every hidden state, 16 sampled token rows of three hidden states and
+    of the final LayerNorm output, 16 sampled attention rows of the first and last layer, logits / loss in fp32 and under
+    the reference's bf16 autocast, per-parameter gradient norms + 64 sampled entries, and a short clipped-AdamW loss
+    trajectory.  Inputs / weights are regenerated from the seeds (checksums stored)."""
+    get_vit_config, SpectraEmbeddings, _ = _import_reference()
+    cfgd = cfg_dict_for(rc, "log_g")
+    sd = refvit.make_state_dict(rc, wseed)
+    flux, _, labels = refvit.make_inputs(rc, batch, xseed)
+    vc, vit, lin = build_reference(cfgd, sd, get_vit_config, SpectraEmbeddings)
+    L, T, D = rc.num_hidden_layers, rc.seq_len, rc.hidden_size
+    with torch.no_grad():
+        o, logits, loss = ref_forward(vc, vit, lin, rc, flux, labels)
+        mine = refvit.forward(rc, sd, flux, labels, output_hidden_states=True, output_attentions=True)
+    errs = {"last": rel(mine.last_hidden_state, o.last_hidden_state), "logits": rel(mine.logits, logits)}
+    for i, (a, b) in enumerate(zip(mine.hidden_states, o.hidden_states)):
+        errs[f"hs{i}"] = rel(a, b)
+    for i, (a, b) in enumerate(zip(mine.attentions, o.attentions)):
+        errs[f"att{i}"] = rel(a, b)
+    print(f"[{tag}] oracle-vs-reference eval fwd at depth {L} x {D}: worst rel err {max(errs.values()):.3e}")
+    assert max(errs.values()) < 5e-5, errs
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ob, logits_b, loss_b = ref_forward(vc, vit, lin, rc, flux, labels)
+    print(f"[{tag}] reference bf16-autocast vs fp32: logits rel {rel(logits_b.float(), logits):.3e} "
+          f"last rel {rel(ob.last_hidden_state.float(), o.last_hidden_state):.3e}")
+
+    vit.eval()
+    _, _, loss2 = ref_forward(vc, vit, lin, rc, flux, labels)
+    loss2.backward()
+    inv = {name_456_to_515(k): k for k in sd if k.startswith("vit.")}
+    ref_grads = {inv[k]: (None if p.grad is None else p.grad.detach().clone()) for k, p in vit.named_parameters()}
+    ref_grads[rc.head_name + ".weight"] = lin.weight.grad.detach().clone()
+    ref_grads[rc.head_name + ".bias"] = lin.bias.grad.detach().clone()
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    refvit.forward(rc, tr.params, flux, labels).loss.backward()
+    gworst = 0.0
+    for k, p in tr.params.items():
+        g = ref_grads[k]
+        if g is None or float(g.norm()) < 1e-6 * (1 + max(float(x.norm()) for x in ref_grads.values() if x is not None)):
+            continue
+        gworst = max(gworst, rel(p.grad, g))
+    print(f"[{tag}] oracle-vs-reference grads: worst rel err {gworst:.3e}")
+    assert gworst < 2e-3, gworst
+    del vit, lin
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    losses, gnorms = [], []
+    for _ in range(steps):
+        losses.append(tr.step(flux, labels))
+        gnorms.append(tr.last_grad_norm)
+
+    rows = sample_idx(batch * T, 16, 7)
+    hs_layers = np.asarray([0, L // 2, L], np.int64)
+    arow = sample_idx(batch * rc.num_attention_heads * T, 16, 8)
+    out = dict(
+        wseed=np.int64(wseed), xseed=np.int64(xseed), batch=np.int64(batch),
+        weight_checksum=np.float64(sum(float(v.double().sum()) for v in sd.values())),
+        flux_checksum=np.float64(flux.double().sum()), labels=labels.numpy(),
+        hs_norms=np.asarray([float(h.double().norm()) for h in o.hidden_states]), hs_layers=hs_layers, rows=rows,
+        hs_rows=np.stack([o.hidden_states[int(i)].reshape(-1, D)[rows].numpy() for i in hs_layers]),
+        last_rows=o.last_hidden_state.reshape(-1, D)[rows].numpy(), last_norm=np.float64(o.last_hidden_state.double().norm()),
+        attn_rows_idx=arow, attn0_rows=o.attentions[0].reshape(-1, T)[arow].numpy(),
+        attn_last_rows=o.attentions[-1].reshape(-1, T)[arow].numpy(),
+        logits=logits.numpy(), loss=np.float32(loss), bf16_logits=logits_b.float().numpy(), bf16_loss=np.float32(loss_b.float()),
+        bf16_last_rows=ob.last_hidden_state.float().reshape(-1, D)[rows].numpy(),
+        step_losses=np.asarray(losses, np.float64), step_grad_norms=np.asarray(gnorms, np.float64),
+    )
+    names = list(sd.keys())
+    out["param_names"] = np.asarray(names)
+    out["grad_norms"] = np.asarray([0.0 if ref_grads[k] is None else float(ref_grads[k].double().norm()) for k in names])
+    out["has_grad"] = np.asarray([ref_grads[k] is not None for k in names])
+    gi, gv = [], []
+    for i, k in enumerate(names):
+        g = ref_grads[k]
+        if g is None:
+            gi.append(np.zeros(64, np.int64)); gv.append(np.zeros(64, np.float32))
+            continue
+        idx = sample_idx(g.numel(), 64, 1000 + i)
+        idx = np.pad(idx, (0, 64 - len(idx)), mode="edge")
+        gi.append(idx); gv.append(g.flatten()[idx].numpy())
+    out["grad_idx"], out["grad_samples"] = np.stack(gi), np.stack(gv)
+    path = os.path.join(ROOT, "tests", "golden", f"{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def make_conv():
+    """Conv1DPatchTokenizer (SURVEY 8f row 2; src/models/tokenization.py:53-69): `num_patches = (L - P) // S + 1` (no
+    padded tail, unlike the sliding-window tokenizer), weight [D, 1, P].  The reference's own module, inside the
+    reference's SpectraEmbeddings, inside the same composition as the other fixtures (proj_fn 'C1D' / 'CNN',
+    embedding.py:33-44); one case with stride == patch, one with stride < patch and a remainder that is dropped."""
+    get_vit_config, SpectraEmbeddings, _ = _import_reference()
+    from src.models.tokenization import Conv1DPatchTokenizer
+
+    out = {}
+    cases = {
+        "a": refvit.RefConfig(image_size=1024, patch_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                              stride_size=32, proj_fn="C1D", loss_name="mae"),
+        "b": refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                              stride_size=40, proj_fn="CNN", num_labels=2, loss_name="l1"),
+    }
+    for tag, rc in cases.items():
+        param = "log_g" if rc.num_labels == 1 else "Teff,log_g"
+        cfgd = cfg_dict_for(rc, param)
+        sd = refvit.make_state_dict(rc, 61)
+        flux, _, labels = refvit.make_inputs(rc, 3, 62)
+        vc, vit, lin = build_reference(cfgd, sd, get_vit_config, SpectraEmbeddings)
+        tk = vit.embeddings.patch_embeddings
+        assert isinstance(tk, Conv1DPatchTokenizer), type(tk)
+        assert tk.num_patches == rc.num_patches == (rc.image_size - rc.patch_size) // rc.stride + 1
+        assert tuple(tk.projection.weight.shape) == (rc.hidden_size, 1, rc.patch_size)
+        with torch.no_grad():
+            o, logits, loss = ref_forward(vc, vit, lin, rc, flux, labels)
+            tok = tk(flux)
+            mine = refvit.forward(rc, sd, flux, labels, output_hidden_states=True)
+        assert rel(mine.tokens, tok) < 2e-6 and rel(mine.logits, logits) < 2e-5, (rel(mine.tokens, tok), rel(mine.logits, logits))
+        vit.eval()
+        _, _, loss2 = ref_forward(vc, vit, lin, rc, flux, labels)
+        loss2.backward()
+        inv = {name_456_to_515(k): k for k in sd if k.startswith("vit.")}
+        grads = {inv[k]: p.grad for k, p in vit.named_parameters() if p.grad is not None}
+        grads[rc.head_name + ".weight"], grads[rc.head_name + ".bias"] = lin.weight.grad, lin.bias.grad
+        tr = refvit.RefTrainer(rc, sd, training=False)
+        refvit.forward(rc, tr.params, flux, labels).loss.backward()
+        gw = max(rel(tr.params[k].grad, g) for k, g in grads.items() if float(g.norm()) > 1e-6)
+        assert gw < 5e-4, gw
+        print(f"[conv/{tag}] {rc.proj_fn}: N={rc.num_patches}; oracle-vs-reference tokens/logits/grads ok (grads {gw:.2e})")
+        out.update({f"{tag}_flux": flux.numpy(), f"{tag}_labels": labels.numpy(), f"{tag}_tokens": tok.numpy(),
+                    f"{tag}_hidden_states": np.stack([h.numpy() for h in o.hidden_states]),
+                    f"{tag}_logits": logits.numpy(), f"{tag}_loss": np.float32(loss), f"{tag}_wseed": np.int64(61)})
+        for k, g in grads.items():
+            out[f"{tag}_grad/{k}"] = g.detach().numpy()
+    path = os.path.join(ROOT, "tests", "golden", "conv.npz")
+    np.savez_compressed(path, **out)
+    print(f"[conv] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
 
 def main():
     torch.manual_seed(0)
@@ -356,7 +493,19 @@ def main():
     make_one("k1", k1, "log_g", 6, 41, 42, True)
     make_rope()
     make_prep()
+    make_conv()
+    # the benchmarked geometries
+    make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
+    make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # regenerate selected fixtures only: python oracle/make_golden.py conv c3 c5
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        for what in sys.argv[1:]:
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv,
+             "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
+             "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
+    else:
+        main()

@@ -21,6 +21,13 @@ CONFIGS = {
                                    pos_encoding_type="learned", loss_name="ce"),
 }
 
+CONV_CONFIGS = {
+    "a": lambda: refvit.RefConfig(image_size=1024, patch_size=32, hidden_size=64, num_hidden_layers=2,
+                                  num_attention_heads=2, stride_size=32, proj_fn="C1D", loss_name="mae"),
+    "b": lambda: refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2,
+                                  num_attention_heads=4, stride_size=40, proj_fn="CNN", num_labels=2, loss_name="l1"),
+}
+
 
 def rel(a, b):
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
@@ -247,3 +254,48 @@ def test_prefilled_attention_weights_match_reference():
     assert sorted(a.state_dict()) == ["k_lin.weight", "q_lin.weight", "v_lin.weight"] and a.out_features == 16
     a.set_qk_trainable(False)
     assert [n for n, p in a.named_parameters() if p.requires_grad] == ["v_lin.weight"]
+
+
+@pytest.mark.parametrize("tag,name", [("c3", "C3"), ("c5", "C5")])
+def test_oracle_reproduces_reference_at_benchmarked_depth(tag, name):
+    """tests/golden/{c3,c5}.npz come from the reference's composition at ViT-B / ViT-L depth (make_golden.make_deep);
+    the restatement must reproduce their norms, sampled rows and logits (eval forward; C5: 24 x 1024 at B = 2)."""
+    rc = refvit.named_config(name)
+    g = np.load(os.path.join(GOLD, f"{tag}.npz"))
+    sd = refvit.make_state_dict(rc, int(g["wseed"]))
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["weight_checksum"])) < 1e-6
+    flux, _, labels = refvit.make_inputs(rc, int(g["batch"]), int(g["xseed"]))
+    assert abs(float(flux.double().sum()) - float(g["flux_checksum"])) < 1e-6
+    with torch.no_grad():
+        out = refvit.forward(rc, sd, flux, labels, output_hidden_states=True, output_attentions=True)
+    D, T = rc.hidden_size, rc.seq_len
+    rows = torch.from_numpy(g["rows"])
+    for h, n in zip(out.hidden_states, g["hs_norms"]):
+        assert abs(float(h.double().norm()) - n) < 1e-5 * n
+    for j, i in enumerate(g["hs_layers"]):
+        assert rel(out.hidden_states[int(i)].reshape(-1, D)[rows], g["hs_rows"][j]) < 1e-5
+    assert rel(out.last_hidden_state.reshape(-1, D)[rows], g["last_rows"]) < 1e-5
+    arow = torch.from_numpy(g["attn_rows_idx"])
+    assert rel(out.attentions[0].reshape(-1, T)[arow], g["attn0_rows"]) < 1e-5
+    assert rel(out.attentions[-1].reshape(-1, T)[arow], g["attn_last_rows"]) < 1e-5
+    assert rel(out.logits, g["logits"]) < 1e-5 and abs(float(out.loss) - float(g["loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_conv_tokenizer_matches_reference(tag):
+    """Conv1DPatchTokenizer (tokenization.py:53-69): num_patches = (L - P) // S + 1, weight [D, 1, P]."""
+    g = np.load(os.path.join(GOLD, "conv.npz"))
+    rc = CONV_CONFIGS[tag]()
+    assert rc.num_patches == (rc.image_size - rc.patch_size) // rc.stride + 1 == g[f"{tag}_tokens"].shape[1]
+    sd = refvit.make_state_dict(rc, int(g[f"{tag}_wseed"]))
+    assert tuple(sd["vit.embeddings.patch_embeddings.projection.weight"].shape) == (rc.hidden_size, 1, rc.patch_size)
+    x, labels = torch.from_numpy(g[f"{tag}_flux"]), torch.from_numpy(g[f"{tag}_labels"])
+    tr = refvit.RefTrainer(rc, sd, training=False)
+    out = refvit.forward(rc, tr.params, x, labels, output_hidden_states=True)
+    out.loss.backward()
+    assert rel(out.tokens.detach(), g[f"{tag}_tokens"]) < 1e-5
+    assert rel(torch.stack(out.hidden_states).detach(), g[f"{tag}_hidden_states"]) < 1e-5
+    assert rel(out.logits.detach(), g[f"{tag}_logits"]) < 1e-5
+    for k, p in tr.params.items():
+        if f"{tag}_grad/{k}" in g.files and float(np.linalg.norm(g[f"{tag}_grad/{k}"])) > 1e-6:
+            assert rel(p.grad, g[f"{tag}_grad/{k}"]) < 5e-4, k

@@ -517,3 +517,58 @@ def test_prefilled_attention_forward_matches_reference(dev):
     for key, kw in {"attn_r16": dict(r=16, scale_by_eigvals=True), "attn_r24_noscale": dict(r=24, scale_by_eigvals=False)}.items():
         m = PrefilledAttention(48, vec, lam, eps=1e-5, **kw).to(dev)
         assert rel(m(x), torch.from_numpy(g[key + "_y"])) < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
+def test_conv1d_tokenizer_matches_reference(dev, tag, precision):
+    """proj_fn 'C1D' / 'CNN' -> Conv1DPatchTokenizer (tokenization.py:53-69): `num_patches = (L - P) // S + 1` (the
+    remainder of the signal is DROPPED, no padded tail patch), weight [D, 1, P].  tests/golden/conv.npz holds the outputs
+    of the reference's own module inside the reference's SpectraEmbeddings: case a = stride == patch, case b = stride <
+    patch with a dropped remainder, 2 regression targets, L1 loss.  Eval forward (tokens, every hidden state, logits,
+    loss) and every gradient (dropout off)."""
+    from oracle import refvit
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    rc = {
+        "a": refvit.RefConfig(image_size=1024, patch_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                              stride_size=32, proj_fn="C1D", loss_name="mae"),
+        "b": refvit.RefConfig(image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                              stride_size=40, proj_fn="CNN", num_labels=2, loss_name="l1"),
+    }[tag]
+    g = np.load(os.path.join(GOLD, "conv.npz"))
+    sd = refvit.make_state_dict(rc, int(g[f"{tag}_wseed"]))
+    cfg = ViTConfig(task_type="reg", image_size=rc.image_size, patch_size=rc.patch_size, hidden_size=rc.hidden_size,
+                    num_hidden_layers=rc.num_hidden_layers, num_attention_heads=rc.num_attention_heads, proj_fn=rc.proj_fn,
+                    stride_size=rc.stride_size, num_labels=rc.num_labels)
+    assert cfg.num_patches == g[f"{tag}_tokens"].shape[1]
+    model = MyViT(cfg, loss_name=rc.loss_name)
+    model.set_precision(precision)
+    assert tuple(model.state_dict()["vit.embeddings.patch_embeddings.projection.weight"].shape) == (rc.hidden_size, 1, rc.patch_size)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    x, labels = torch.from_numpy(g[f"{tag}_flux"]).to(dev), torch.from_numpy(g[f"{tag}_labels"]).to(dev)
+    out = model(x, labels=labels, output_hidden_states=True)
+    T = lambda k: torch.from_numpy(g[f"{tag}_{k}"])
+    tol = 1e-4 if precision == "32" else 1.5e-2
+    e_tok = rel(out.hidden_states[0][:, 1:], T("tokens"))
+    e_hs = rel(torch.stack([h.cpu() for h in out.hidden_states]), T("hidden_states"))
+    e_log = rel(out.logits, T("logits"))
+    assert e_tok < (1e-4 if precision == "32" else 6e-3) and e_hs < tol and e_log < (1e-4 if precision == "32" else 2e-2), (e_tok, e_hs, e_log)
+    assert abs(float(out.loss) - float(g[f"{tag}_loss"])) <= (2e-4 if precision == "32" else 3e-2) * float(g[f"{tag}_loss"]) + 1e-5
+    model(x, labels=labels).loss.backward()
+    worst = 0.0
+    gtol = 2e-4 if precision == "32" else 4e-2
+    for name, p in model.named_parameters():
+        key = f"{tag}_grad/{name}"
+        if key not in g.files:
+            assert p.grad is None, name
+            continue
+        ref = torch.from_numpy(g[key])
+        if float(ref.norm()) < 1e-6:
+            continue
+        e = rel(p.grad.reshape(ref.shape), ref)
+        worst = max(worst, e)
+        assert e < gtol, (name, e)
+    print(f"[conv/{tag} {precision}] tokens {e_tok:.2e}, hidden states {e_hs:.2e}, logits {e_log:.2e}, worst grad {worst:.2e}")
