@@ -170,6 +170,19 @@ int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void
 int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
                              float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream);
+/* Training pair with the context kept to ~16 mantissa bits.  ctx_lo (bf16 [B*T, H*dh], may be NULL = the calls above):
+ * the forward also stores the rounding residual ctx_exact - bf16(ctx_exact); the backward forms
+ * delta = rowsum(dctx * (ctx + ctx_lo)).  Why: the softmax backward is dS = P o (dP - delta); the reference (autocast,
+ * vit_with_rope.py:63-81 under basemodule.py:233) takes delta = sum_j P_j dP_j in fp32, which cancels exactly against dP.
+ * rowsum(dctx * ctx) with an 8-bit ctx is off by an amount COMMON to a score row, which survives the sum over keys in dQ / dK
+ * once token representations share a large common component (deep layers): 5e-2 on ViT-L's late query weights against
+ * the reference's own bf16 1.1e-2; with the residual 1e-2 or better (tests/test_parity_deep_gpu.py).  dqkv_colsum may be
+ * NULL.  io_dtype = VIT_F32 ignores ctx_lo. */
+int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo, float* lse, int io_dtype, int B, int H,
+                         int T, int dh, float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream);
+int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const void* ctx_lo, const void* dctx,
+                         const float* lse, float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                         float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream);
 /* Attention probabilities [B, H, T, T] f32 (eval-mode, for output_attentions=True: specvit.py:92-93). */
 int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtype, int B, int H, int T, int dh,
                         float scale, vit_stream stream);

@@ -372,13 +372,33 @@ def make_deep(tag, rc, batch, wseed, xseed, steps=2):
     tr = refvit.RefTrainer(rc, sd, training=False)
     refvit.forward(rc, tr.params, flux, labels).loss.backward()
     gworst = 0.0
+    gmax = max(float(x.norm()) for x in ref_grads.values() if x is not None)
     for k, p in tr.params.items():
         g = ref_grads[k]
-        if g is None or float(g.norm()) < 1e-6 * (1 + max(float(x.norm()) for x in ref_grads.values() if x is not None)):
+        if g is None or float(g.norm()) < 1e-6 * (1 + gmax):
             continue
         gworst = max(gworst, rel(p.grad, g))
     print(f"[{tag}] oracle-vs-reference grads: worst rel err {gworst:.3e}")
     assert gworst < 2e-3, gworst
+    # the reference's OWN bf16-autocast gradients (precision='bf16-mixed': autocast forward, backward through it): how far
+    # they sit from its fp32 gradients is the yardstick for the bf16 gradient gate at this depth
+    for p in list(vit.parameters()) + list(lin.parameters()):
+        p.grad = None
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        _, _, loss_bg = ref_forward(vc, vit, lin, rc, flux, labels)
+    loss_bg.float().backward()
+    bf16_grads = {inv[k]: (None if p.grad is None else p.grad.detach().float()) for k, p in vit.named_parameters()}
+    bf16_grads[rc.head_name + ".weight"] = lin.weight.grad.detach().float()
+    bf16_grads[rc.head_name + ".bias"] = lin.bias.grad.detach().float()
+    bf16_err = {}
+    for k, g in ref_grads.items():
+        if g is None or float(g.norm()) < 1e-6 * (1 + gmax):
+            bf16_err[k] = 0.0
+        else:
+            bf16_err[k] = rel(bf16_grads[k], g)
+    kw = max(bf16_err, key=bf16_err.get)
+    print(f"[{tag}] reference bf16-autocast gradients vs its fp32 gradients: worst rel {bf16_err[kw]:.3e} ({kw}), "
+          f"median {float(np.median([v for v in bf16_err.values() if v > 0])):.3e}")
     del vit, lin
     tr = refvit.RefTrainer(rc, sd, training=False)
     losses, gnorms = [], []
@@ -406,6 +426,7 @@ def make_deep(tag, rc, batch, wseed, xseed, steps=2):
     out["param_names"] = np.asarray(names)
     out["grad_norms"] = np.asarray([0.0 if ref_grads[k] is None else float(ref_grads[k].double().norm()) for k in names])
     out["has_grad"] = np.asarray([ref_grads[k] is not None for k in names])
+    out["bf16_grad_err"] = np.asarray([bf16_err.get(k, 0.0) for k in names])
     gi, gv = [], []
     for i, k in enumerate(names):
         g = ref_grads[k]

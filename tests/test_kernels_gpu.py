@@ -683,3 +683,37 @@ def test_gemm_half_tile_tail(dev, M, N, K):
     assert torch.equal(ge[0][0], ge[2][0]) and torch.equal(ge[0][1], ge[2][1])
     assert rel(outs[1][1], x.float() @ W.float().t()) < 4e-3
     assert rel(outs[1][2], dy.float() @ W2.float()) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(1, 2, 197, 64), (1, 2, 577, 64), (1, 1, 640, 64)])
+def test_attention_delta_residual(dev, B, H, T, dh):
+    """vit_attention_fwd_lo / vit_attention_bwd_lo: with value rows that share a large common component (what deep layers
+    of a transformer look like), delta = rowsum(dO * O) from the 8-bit O is off by an amount common to each score row, which
+    the sum over keys in dQ / dK does not average out.  The stored residual O - bf16(O) must (a) reconstruct O to 2^-15,
+    (b) leave ctx itself unchanged, (c) bring dQ / dK to the level of the fp32 formula -- resident (197, 577) and tiled
+    (640) kernels."""
+    import vit_amd.functional as vf
+
+    scale = dh ** -0.5
+    qkv = randn((B * T, 3, H, dh), dev, 60, 0.5)
+    qkv[:, 2] += 8.0 * randn((1, H, dh), dev, 61)  # common component of every value row
+    qkv = bf(qkv.reshape(B * T, 3 * H * dh))
+    ctx0, lse0 = vf.attention_fwd(qkv, B, H, T, dh, scale)
+    lo = torch.empty_like(ctx0)
+    ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, scale, ctx_lo=lo)
+    assert torch.equal(ctx, ctx0) and torch.equal(lse, lse0)
+    q32 = qkv.double().requires_grad_(True)
+    ref, _, _ = attn_ref(q32, B, H, T, dh, scale)
+    # bf16 probabilities feed the PV product, so O itself carries ~2e-3; the residual must capture the ROUNDING of that O
+    assert rel(ctx.double() + lo.double(), ref) < rel(ctx, ref)
+    assert float((lo.float().abs() <= ctx.float().abs() * 2.0 ** -8 + 1e-30).float().mean()) == 1.0
+    dctx = bf(randn((B * T, H * dh), dev, 62))
+    ref.backward(dctx.double())
+    g = q32.grad.view(B * T, 3, H * dh)
+    d0 = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale).double().view(B * T, 3, H * dh)
+    d1 = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale, ctx_lo=lo).double().view(B * T, 3, H * dh)
+    e0 = [rel(d0[:, i], g[:, i]) for i in range(3)]
+    e1 = [rel(d1[:, i], g[:, i]) for i in range(3)]
+    print(f"[T={T}] dq/dk/dv rel err without residual {e0[0]:.2e}/{e0[1]:.2e}/{e0[2]:.2e}, with {e1[0]:.2e}/{e1[1]:.2e}/{e1[2]:.2e}")
+    assert e1[0] < 0.5 * e0[0] and e1[1] < 0.5 * e0[1], (e0, e1)
+    assert max(e1) < 1.5e-2, e1

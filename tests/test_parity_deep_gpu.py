@@ -12,7 +12,8 @@ Two checkers per case:
 
 Tolerances: the same gates as tests/test_parity_gpu.py.  precision '32': rel-L2 <= 1e-4 forward (north_star asks 1e-3),
 2e-4 per gradient tensor.  precision 'bf16-mixed': hidden states <= 1.5e-2, logits no worse than 1.5 x the reference's
-own bf16-autocast error + 1e-3, gradients rel <= 4e-2 with cosine >= 0.999.  Batch 4 / 5 (C3) and 2 (C5) give 788 / 985 /
+own bf16-autocast error + 1e-3; gradients: every tensor within 1.5 x the WORST per-tensor error of the reference's own
+bf16-autocast gradients at that depth (fixture `bf16_grad_err`: 1.4e-2 at C3, 1.1e-2 at C5) + 2e-3, cosine >= 0.999.  Batch 4 / 5 (C3) and 2 (C5) give 788 / 985 /
 1154 token rows: all three run the GEMMs on zero-padded 256-row tiles, which is the padded-row case at the real T.
 """
 import os
@@ -54,7 +55,7 @@ def oracle_run(tag, batch=None):
     tr = refvit.RefTrainer(rc, sd, training=False)
     out = refvit.forward(rc, tr.params, flux, labels, output_hidden_states=True, output_attentions=True)
     out.loss.backward()
-    res = dict(rc=rc, g=g, sd=sd, flux=flux, labels=labels,
+    res = dict(rc=rc, g=g, sd=sd, flux=flux, labels=labels, ref_bf16_grad_err=g["bf16_grad_err"],
                hs=[h.detach() for h in out.hidden_states], last=out.last_hidden_state.detach(),
                attn0=out.attentions[0].detach(), attnL=out.attentions[-1].detach(),
                logits=out.logits.detach(), loss=float(out.loss.detach()),
@@ -120,6 +121,9 @@ def _check_grads(model, o, precision, tag):
     names = [str(n) for n in g["param_names"]] if g is not None else None
     worst, worst_name, worst_cos = 0.0, "", 1.0
     tol, tol_cos = (2e-4, 1 - 1e-7) if precision == "32" else (4e-2, 0.999)
+    ref_bf16 = float(np.max(o["ref_bf16_grad_err"]))
+    if precision != "32":
+        tol = 1.5 * ref_bf16 + 2e-3
     gmax = max(float(v.norm()) for v in o["grads"].values() if v is not None)
     for name, p in model.named_parameters():
         ref = o["grads"][name]
@@ -143,7 +147,8 @@ def _check_grads(model, o, precision, tag):
             idx = torch.from_numpy(g["grad_idx"][i])
             es = rel(mine[idx], g["grad_samples"][i])
             assert es < 3 * tol + 1e-6, (name, es)
-    print(f"[{tag} {precision}] worst gradient rel err {worst:.2e} ({worst_name}), worst cosine {worst_cos:.6f}")
+    print(f"[{tag} {precision}] worst gradient rel err {worst:.2e} ({worst_name}), worst cosine {worst_cos:.6f}; "
+          f"the reference's own bf16-autocast gradients: worst {ref_bf16:.2e}")
 
 
 @pytest.mark.parametrize("tag", ["c3", "c5"])

@@ -66,6 +66,8 @@ _PROTOS = {
     "vit_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
     "vit_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
     "vit_attention_bwd_colsum": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P, _P],
+    "vit_attention_fwd_lo": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P],
+    "vit_attention_bwd_lo": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U64, _U64, _P, _P],
     "vit_attention_probs": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vit_unfold_cast": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vit_fold_add": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -31,6 +31,9 @@ constexpr float LN2 = 0.6931471805599453f;
 
 struct AttnArgs {
   const short* qkv; short* ctx; float* lse;
+  short* ctx_lo;  // optional bf16 [B*T, H*dh]: the rounding residual ctx_exact - bf16(ctx_exact), so that the backward's
+                  // delta = rowsum(dO * O) sees O to ~16 mantissa bits (with the 8-bit O its error is common to a whole
+                  // score row and survives the sum over keys in dQ / dK: measured 5e-2 on ViT-L's deep query weights)
   const short* dctx; float* delta; short* dqkv;
   int B, H, T, dh;
   float scale;
@@ -96,6 +99,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+// lo = bf16(v - bf16(v)) for 4 values already packed as pk
+__device__ __forceinline__ void store_lo(short* dst, const f32x4& v, const u32x2& pk) {
+  const float h0 = __builtin_bit_cast(float, pk[0] << 16), h1 = __builtin_bit_cast(float, pk[0] & 0xFFFF0000u);
+  const float h2 = __builtin_bit_cast(float, pk[1] << 16), h3 = __builtin_bit_cast(float, pk[1] & 0xFFFF0000u);
+  u32x2 lo = {pack2bf(v[0] - h0, v[1] - h1), pack2bf(v[2] - h2, v[3] - h3)};
+  *(u32x2*)dst = lo;
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int DH>
@@ -197,6 +207,7 @@ __global__ __launch_bounds__(AW * 64) void attn_fwd_kernel(AttnArgs p) {
         const f32x4 v = ot[dt] * inv;
         u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
         *(u32x2*)(o + d) = pk;
+        if (p.ctx_lo) store_lo(p.ctx_lo + (o - p.ctx) + d, v, pk);
       }
     }
     if (lg == 0) p.lse[(long)bh * T + q] = (m + log2f(l)) * LN2;
@@ -237,6 +248,11 @@ __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
         const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) del += bf2f(o[e]) * bf2f(dof[s][e]);
+        if (p.ctx_lo) {
+          const bf16x8 ol = *(const bf16x8*)(p.ctx_lo + (ob - p.ctx) + (long)q * ldc + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) del += bf2f(ol[e]) * bf2f(dof[s][e]);
+        }
       }
     }
     del += __shfl_xor(del, 16, 64);
@@ -623,6 +639,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
           const f32x4 v = ot[rq][dt] * inv;
           u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *(u32x2*)(o + d) = pk;
+          if (p.ctx_lo) store_lo(p.ctx_lo + (o - p.ctx) + d, v, pk);
         }
       }
       if (lg == 0) p.lse[(long)bh * T + q] = (m[rq] + log2f(lt)) * LN2;
@@ -674,6 +691,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
         const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d_ += bf2f(o[e]) * bf2f(dof[rq][s][e]);
+        if (p.ctx_lo) {
+          const bf16x8 ol = *(const bf16x8*)(p.ctx_lo + (ob - p.ctx) + (long)q * ldc + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d_ += bf2f(ol[e]) * bf2f(dof[rq][s][e]);
+        }
       }
     }
     d_ = grp4_sum(d_);
@@ -948,12 +970,13 @@ static void res_geometry(int T, int* nsplit, int* wpw) {
   *nsplit = cdiv(nw, *wpw);
 }
 
-template <typename F>
-static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
-  // dynamic LDS above 64 KiB needs the attribute; set it to the CU's 160 KiB once per kernel
+template <void (*FN)(AttnArgs)>
+static int launch_res(const AttnArgs& a, size_t smem, hipStream_t st) {
+  // dynamic LDS above 64 KiB needs the attribute; set it to the CU's 160 KiB once per KERNEL (the template parameter is the
+  // kernel itself, not its type: all resident kernels share one function-pointer type)
   static bool done = false;
   if (!done) {
-    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VIT_HIP(hipFuncSetAttribute((const void*)FN, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   // several workgroups per (batch, head), each staging the whole K / V (or Q / dO) but owning a share of the row tiles:
@@ -961,15 +984,15 @@ static int launch_res(F fn, const AttnArgs& a, size_t smem, hipStream_t st) {
   // staging latency of one hides behind the key loops of the others; one 7-wave workgroup per CU paid it in the open.
   AttnArgs b = a;
   res_geometry(a.T, &b.nsplit, &b.wpw);
-  hipLaunchKernelGGL(fn, dim3(a.B * a.H * b.nsplit), dim3(b.wpw * 64), smem, st, b);
+  hipLaunchKernelGGL(FN, dim3(a.B * a.H * b.nsplit), dim3(b.wpw * 64), smem, st, b);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
 
 #define DISPATCH_RES(KERNEL, a, smem_expr, st, rc)                                          \
   do {                                                                                      \
-    if (a.dh <= 32) { constexpr int DH_ = 32; rc = launch_res(KERNEL<32, RES_RQ>, a, smem_expr, st); }        \
-    else { constexpr int DH_ = 64; rc = launch_res(KERNEL<64, RES_RQ>, a, smem_expr, st); }                    \
+    if (a.dh <= 32) { constexpr int DH_ = 32; rc = launch_res<KERNEL<32, RES_RQ>>(a, smem_expr, st); }        \
+    else { constexpr int DH_ = 64; rc = launch_res<KERNEL<64, RES_RQ>>(a, smem_expr, st); }                    \
   } while (0)
 
 // ======================================================================================= fp32 attention (precision '32')
@@ -1166,6 +1189,11 @@ using namespace vit;
 
 int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int io_dtype, int B, int H, int T, int dh,
                       float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
+  return vit_attention_fwd_lo(h, qkv, ctx, nullptr, lse, io_dtype, B, H, T, dh, scale, dropout_p, seed, site, stream);
+}
+
+int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo, float* lse, int io_dtype, int B, int H,
+                         int T, int dh, float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && ctx && lse, VIT_ERR_ARG, "vit_attention_fwd: null pointer");
   int rc = check_attn("vit_attention_fwd", B, H, T, dh, dropout_p);
@@ -1178,11 +1206,10 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
     return launch_attn32(0, a32, (hipStream_t)stream);
   }
   AttnArgs a = {};
-  a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.lse = lse;
+  a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.ctx_lo = (short*)ctx_lo; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
-    const size_t ntl = cdiv(T, RT);
     DISPATCH_RES(attn_fwd_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), (hipStream_t)stream, rc);
     return rc;
   }
@@ -1192,21 +1219,31 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
   return VIT_OK;
 }
 
-static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
-                              float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream);
+static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* ctx_lo, const void* dctx,
+                              const float* lse, float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh,
+                              float scale, float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream);
 
 int vit_attention_bwd(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                       float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
                       float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
-  return attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site, nullptr,
-                            stream);
+  return attention_bwd_impl(h, qkv, ctx, nullptr, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+                            nullptr, stream);
 }
 
 int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
                              float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream) {
   VIT_CHECK(dqkv_colsum, VIT_ERR_ARG, "vit_attention_bwd_colsum: null dqkv_colsum");
+  return vit_attention_bwd_lo(h, qkv, ctx, nullptr, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+                              dqkv_colsum, stream);
+}
+
+int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const void* ctx_lo, const void* dctx,
+                         const float* lse, float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
+                         float dropout_p, uint64_t seed, uint64_t site, float* dqkv_colsum, vit_stream stream) {
+  if (!dqkv_colsum)
+    return attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+                              nullptr, stream);
   const int D3 = 3 * H * dh;
   if (io_dtype == VIT_BF16 && T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && (dh % 4) == 0 && res_fits(T, dh)) {
     int nsplit, wpw;
@@ -1216,21 +1253,21 @@ int vit_attention_bwd_colsum(vit_handle h, const void* qkv, const void* ctx, con
     const int prow = B * nsplit * wpw;
     if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
       // the resident kernels leave one partial row per wave: column sums of what they stored
-      int rc = attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
-                                  part, stream);
+      int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed,
+                                  site, part, stream);
       if (rc != VIT_OK) return rc;
       return launch_reduce_partials(part, prow, D3, dqkv_colsum, D3, dqkv_colsum, 0, (hipStream_t)stream);
     }
   }
-  int rc = attention_bwd_impl(h, qkv, ctx, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
+  int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed, site,
                               nullptr, stream);
   if (rc != VIT_OK) return rc;
   return vit_colsum(h, dqkv, io_dtype, D3, dqkv_colsum, B * T, D3, 0, stream);
 }
 
-static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* dctx, const float* lse,
-                              float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh, float scale,
-                              float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream) {
+static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* ctx_lo, const void* dctx,
+                              const float* lse, float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh,
+                              float scale, float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream) {
   (void)h;
   VIT_CHECK(qkv && ctx && dctx && lse && delta && dqkv, VIT_ERR_ARG, "vit_attention_bwd: null pointer");
   int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
@@ -1248,12 +1285,12 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   }
   AttnArgs a = {};
   a.qkv = (const short*)qkv; a.lse = const_cast<float*>(lse); a.ctx = (short*)const_cast<void*>(ctx);
+  a.ctx_lo = (short*)const_cast<void*>(ctx_lo);
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop(dropout_p, seed, site);
   a.csum_part = colsum_part;
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
-    const size_t ntl = cdiv(T, RT);
     DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
     DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 2 * (size_t)((T + 15) & ~15) * 4), st, rc);

@@ -272,6 +272,8 @@ class ViTEngine:
             x=[E((B, T, D), f32) for _ in range(L + 1)],
             h1=[G(D, b16) for _ in range(nl)], qkv=[G(3 * D, b16) for _ in range(nl)],
             ctx=[G(D, b16) for _ in range(nl)], lse=[E((B * H, T), f32) for _ in range(nl)],
+            # bf16 training: the rounding residual of ctx, so the backward's delta sees the context to ~16 bits (vit_amd.h)
+            ctx_lo=[E((M, D), b16) if (train and self.precision == "bf16") else None for _ in range(nl)],
             x1=[E((M, D), f32) for _ in range(nl)], h2=[G(D, b16) for _ in range(nl)],
             u=[G(Fd, b16) for _ in range(nl)], g=[G(Fd, b16) for _ in range(nl)],
             mean1=[E((M,), f32) for _ in range(nl)], rstd1=[E((M,), f32) for _ in range(nl)],
@@ -357,7 +359,7 @@ class ViTEngine:
             if rope is not None:  # vit_with_rope.py:58-60: q, k rotated per head before the scores
                 vf.rope_qk(a["qkv"][j], rope[0], rope[1], T, H, dh)
             vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
-                             lse=a["lse"][j])
+                             lse=a["lse"][j], ctx_lo=a["ctx_lo"][j])
             if output_attentions:
                 atts.append(vf.attention_probs(a["qkv"][j], B, H, T, dh, scale))
             vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, out=y,
@@ -448,7 +450,7 @@ class ViTEngine:
             # sits in between (then after the inverse rotation, by the column-sum kernel)
             vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
                              dropout=(pa, seed, self._site(i, 0)), dqkv=t["dqkv"], delta=t["delta"],
-                             colsum_out=None if rope is not None else self._qkv_bias(i, self.grads))
+                             colsum_out=None if rope is not None else self._qkv_bias(i, self.grads), ctx_lo=a["ctx_lo"][i])
             if rope is not None:  # gradient wrt the un-rotated q, k: the inverse rotation
                 vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
                 vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))

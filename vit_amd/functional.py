@@ -170,19 +170,24 @@ def layernorm_bwd_fused(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, dyn, 
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP, ctx=None, lse=None):
+def attention_fwd(qkv, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP, ctx=None, lse=None,
+                  ctx_lo=None):
+    """ctx_lo (bf16, like ctx): also store the rounding residual of the context for the backward's delta (vit_amd.h)."""
     h = _h(qkv)
     ctx = ctx if ctx is not None else torch.empty((B * T, H * dh), dtype=qkv.dtype, device=qkv.device)
     lse = lse if lse is not None else torch.empty((B * H, T), dtype=torch.float32, device=qkv.device)
     p, seed, site = dropout
-    check(h.lib.vit_attention_fwd(h.h, qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale,
-                                  p, seed, site, _stream(qkv)), "vit_attention_fwd")
+    if ctx_lo is not None:
+        _chk(ctx_lo, ctx.dtype, "attention_fwd ctx_lo")
+    check(h.lib.vit_attention_fwd_lo(h.h, qkv.data_ptr(), ctx.data_ptr(), _ptr(ctx_lo), lse.data_ptr(), _DT[qkv.dtype], B, H,
+                                     T, dh, scale, p, seed, site, _stream(qkv)), "vit_attention_fwd")
     return ctx, lse
 
 
 def attention_bwd(qkv, ctx, dctx, lse, B: int, H: int, T: int, dh: int, scale: float, dropout: Dropout = NO_DROP,
-                  dqkv=None, delta=None, colsum_out=None):
-    """colsum_out (f32 [3*H*dh]): also the column sums of dqkv (the QKV projection's bias gradient)."""
+                  dqkv=None, delta=None, colsum_out=None, ctx_lo=None):
+    """colsum_out (f32 [3*H*dh]): also the column sums of dqkv (the QKV projection's bias gradient).
+    ctx_lo: the residual attention_fwd(ctx_lo=...) stored."""
     _chk(dctx, qkv.dtype, "attention_bwd dctx")
     h = _h(qkv)
     dqkv = dqkv if dqkv is not None else torch.empty_like(qkv)
@@ -191,13 +196,9 @@ def attention_bwd(qkv, ctx, dctx, lse, B: int, H: int, T: int, dh: int, scale: f
     if colsum_out is not None:
         _chk(colsum_out, torch.float32, "attention_bwd colsum_out")
         h.ensure_workspace(B * 16 * 3 * H * dh * 4)
-        check(h.lib.vit_attention_bwd_colsum(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
-                                             delta.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed,
-                                             site, colsum_out.data_ptr(), _stream(qkv)), "vit_attention_bwd_colsum")
-        return dqkv
-    check(h.lib.vit_attention_bwd(h.h, qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                  dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed, site, _stream(qkv)),
-          "vit_attention_bwd")
+    check(h.lib.vit_attention_bwd_lo(h.h, qkv.data_ptr(), ctx.data_ptr(), _ptr(ctx_lo), dctx.data_ptr(), lse.data_ptr(),
+                                     delta.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], B, H, T, dh, scale, p, seed, site,
+                                     _ptr(colsum_out), _stream(qkv)), "vit_attention_bwd")
     return dqkv
 
 
