@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """`scripts/run.py` of the reference (scripts/run.py:14-54) on the MI355X path: same arguments (-f/--config, -w, --save,
 -g, --debug, --ckpt, --seed), same seeding and config plumbing, `Experiment(...).run()` replaced by the build's module +
-trainer.  The reference's HDF5 datasets are out of scope, so data comes from `--synthetic N`
-seeded spectra with the reference's batch contract (flux, error, labels)."""
+trainer.  `--save` keeps the best-by-monitor checkpoint and `last.ckpt` under $CKPT_DIR (vit.py:386-414); `--ckpt` resumes
+(vit.py:464); `-g N` starts N rank processes itself.  The reference's HDF5 datasets are out of scope (SURVEY.md section 2
+#10), so data comes from `--synthetic N` seeded spectra with the reference's batch contract (flux, error, labels)."""
 import argparse
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-import torch
+import torch  # importing torch does not touch the GPU; the launcher parent below never calls into torch.cuda
 
 from vit_amd.module import ViTLModule
 from vit_amd.trainer import Trainer, seed_everything
@@ -61,40 +62,44 @@ class SyntheticSpectra:
             yield self.flux[j], self.error[j], self.labels[j]
 
 
-def main(args):
+def build(args, for_test=False):
     seed_everything(args.seed)
     config = load_config(args.config)
     if args.gpu is None:
         args.gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    config.setdefault("train", {})
-    config["train"]["gpus"] = args.gpu
-    config["train"]["debug"] = args.debug
-    config["train"]["save"] = args.save
-    print(f"[Setup] Random seed: {args.seed}")
-    print("[Setup] Deterministic mode: ON")
+    train = config.setdefault("train", {})
+    train["gpus"] = args.gpu
+    train["debug"] = args.debug
+    train["save"] = False if for_test else bool(getattr(args, "save", False))  # pure evaluation never saves (test.py:41)
     module = ViTLModule(config=config)
-    if args.ckpt:
-        sd = torch.load(args.ckpt, map_location="cpu", weights_only=True)
-        sd = sd.get("state_dict", sd)
-        module.model.load_state_dict({k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()})
     m = config["model"]
-    bs = config["train"].get("batch_size", 64)
-    mk = lambda n, seed, shuffle: SyntheticSpectra(n, m["image_size"], bs, m["task_type"], module.model.config.num_labels,
-                                                   seed, shuffle)
-    train, val = mk(args.synthetic, 1, not args.debug), mk(max(bs, args.synthetic // 8), 2, False)
+    bs = train.get("batch_size", 64)
+
+    def spectra(n, seed, shuffle):
+        return SyntheticSpectra(n, m["image_size"], bs, m["task_type"], module.model.config.num_labels, seed, shuffle)
+
+    return config, module, spectra
+
+
+def main(args):
+    """`launch.sh run`: fit (optionally resuming from --ckpt: weights, optimizer, scheduler, epoch), then test."""
+    config, module, spectra = build(args)
+    n_eval = max(config["train"].get("batch_size", 64), args.synthetic // 8)
     trainer = Trainer(config["train"])
-    hist = trainer.fit(module, train, val)
-    test_logs = trainer.test(module, mk(max(bs, args.synthetic // 8), 3, False))
+    hist = trainer.fit(module, spectra(args.synthetic, 1, not args.debug), spectra(n_eval, 2, False), ckpt_path=args.ckpt)
+    test_logs = trainer.test(module, spectra(n_eval, 3, False))
     if trainer.rank == 0:
         print("[test] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(test_logs.items())))
-        if args.save:
-            ckpt_dir = os.environ.get("CKPT_DIR", "./checkpoints")
-            os.makedirs(ckpt_dir, exist_ok=True)
-            path = os.path.join(ckpt_dir, f"{module.model.name}-last.pt")
-            torch.save({k: v.cpu() for k, v in module.model.state_dict().items()}, path)
-            print(f"[save] {path}")
+        if trainer.checkpointer is not None:
+            print(f"[save] best {trainer.checkpointer.best_path} ({trainer.checkpointer.monitor}="
+                  f"{trainer.checkpointer.best_score}); last {trainer.checkpointer.last_path}")
     return hist
 
 
 if __name__ == "__main__":
-    main(parse_args())
+    a = parse_args()
+    from vit_amd.launch import launch_ranks, under_launcher
+
+    if a.gpu and a.gpu > 1 and not under_launcher():  # one command -> N ranks (hardware_utils.py:86-95 'ddp')
+        sys.exit(launch_ranks(a.gpu, os.path.abspath(__file__), sys.argv[1:]))
+    main(a)

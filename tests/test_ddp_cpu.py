@@ -46,6 +46,24 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(g[n:], torch.arange(lay.n_total, dtype=torch.float32)[n:] * (rank + 1))
     covered = sorted(lay.buckets())
     ok = ok and covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    # 'zero1': sharded buckets leave the mean in the rank's shard (gloo: all-reduce underneath), the others everywhere;
+    # all_gather_params then rebuilds identical full buffers from the owners' slices
+    g2 = torch.arange(lay.n_total, dtype=torch.float32) * (rank + 1)
+    z = d.ShardedGradReducer(lambda: g2, lay.buckets())
+    assert z.mode == "zero1" and any(z.sharded) and not all(z.sharded)
+    for lo, hi in lay.buckets():
+        z.bucket_ready(lo, hi)
+    z.finish()
+    for (lo, hi), sh in zip(lay.buckets(), z.sharded):
+        a, b = z.shard(lo, hi) if sh else (lo, hi)
+        ok = ok and torch.allclose(g2[a:b], expect[a:b])
+        ok = ok and (not sh or (b - a) * world == hi - lo)
+    flat2 = torch.zeros(lay.n_total)
+    for (lo, hi), sh in zip(lay.buckets(), z.sharded):
+        a, b = z.shard(lo, hi) if sh else (lo, hi)
+        flat2[a:b] = torch.arange(lay.n_total, dtype=torch.float32)[a:b] + 1.0  # "updated" only where this rank owns
+    z.all_gather_params(flat2)
+    ok = ok and torch.equal(flat2[:n], torch.arange(lay.n_total, dtype=torch.float32)[:n] + 1.0)
     idx = d.shard_indices(11, rank, world, epoch=3, shuffle=True, seed=42)
     q.put((rank, bool(ok), idx.tolist(), red.bytes_reduced))
     dist.barrier()

@@ -1,0 +1,125 @@
+"""CPU suite for the host-side mirror of the reference surface that needs no kernel: epoch metrics, residual statistics,
+config loading, run names of the model factory, checkpoint bookkeeping."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_metrics_match_definitions_and_accumulate():
+    from vit_amd.metrics import Accuracy, MeanAbsoluteError, MeanSquaredError, R2Score
+
+    g = torch.Generator().manual_seed(0)
+    t = torch.rand(100, generator=g)
+    p = t + 0.1 * torch.randn(100, generator=g)
+    mae, mse, r2 = MeanAbsoluteError(), MeanSquaredError(), R2Score()
+    chunks = [(0, 30), (30, 64), (64, 100)]
+    for a, b in chunks:
+        v_mae, v_mse, v_r2 = mae(p[a:b], t[a:b]), mse(p[a:b], t[a:b]), r2(p[a:b], t[a:b])
+        tt, pp = t[a:b].double(), p[a:b].double()
+        assert abs(float(v_mae) - float((pp - tt).abs().mean())) < 1e-6      # the call returns the BATCH value
+        assert abs(float(v_r2) - (1 - float(((tt - pp) ** 2).sum() / ((tt - tt.mean()) ** 2).sum()))) < 1e-5
+    td, pd = t.double(), p.double()
+    assert abs(float(mae.compute()) - float((pd - td).abs().mean())) < 1e-6  # compute() is over everything seen
+    assert abs(float(mse.compute()) - float(((pd - td) ** 2).mean())) < 1e-6
+    assert abs(float(r2.compute()) - (1 - float(((td - pd) ** 2).sum() / ((td - td.mean()) ** 2).sum()))) < 1e-5
+    assert mae.n == 3
+    mae.reset()
+    assert mae.n == 0
+    with pytest.raises(RuntimeError):
+        mae.compute()
+    acc = Accuracy()
+    logits = torch.tensor([[2.0, 1.0, 0.0], [0.0, 3.0, 1.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+    assert float(acc(logits, torch.tensor([0, 1, 0, 0]))) == 0.75 and float(acc.compute()) == 0.75
+
+
+def test_residual_stats_match_numpy():
+    from vit_amd.module import ViTLModule
+
+    rng = np.random.default_rng(1)
+    for n in (7, 40):
+        lab = rng.random(n)
+        pred = 0.2 + 0.8 * lab + 0.05 * rng.standard_normal(n)
+        st = ViTLModule._residual_stats(torch.from_numpy(pred), torch.from_numpy(lab))
+        res = pred - lab
+        assert abs(st["bias_median"] - np.median(res)) < 1e-12
+        assert abs(st["p90"] - np.percentile(np.abs(res), 90)) < 1e-12
+        assert abs(st["beta"] - np.polyfit(lab, pred, 1)[0]) < 1e-9
+
+
+def test_load_config_expands_and_rejects_wandb(tmp_path, monkeypatch):
+    from vit_amd.utils import load_config
+
+    monkeypatch.setenv("VIT_TEST_ROOT", "/data/x")
+    f = tmp_path / "c.yaml"
+    f.write_text("data:\n  file_path: ${VIT_TEST_ROOT}/train.h5\n  list: ['~/a', 3]\nmodel:\n  hidden_size: 32\n")
+    cfg = load_config(str(f))
+    assert cfg["data"]["file_path"] == "/data/x/train.h5"
+    assert cfg["data"]["list"] == [os.path.expanduser("~/a"), 3] and cfg["model"]["hidden_size"] == 32
+    w = tmp_path / "w.yaml"
+    w.write_text("_wandb:\n  value: {}\nmodel:\n  value:\n    hidden_size: 32\n")
+    with pytest.raises(ValueError, match="W&B"):
+        load_config(str(w))
+    e = tmp_path / "e.yaml"
+    e.write_text("")
+    assert load_config(str(e)) == {}
+
+
+def test_model_factory_names_and_errors(tmp_path):
+    """Run names carry the preprocessor tag (builder.py:45-133); errors keep the reference's types."""
+    from vit_amd.builder import _build_preprocessor, get_model
+
+    g = torch.Generator().manual_seed(3)
+    q, _ = torch.linalg.qr(torch.randn(64, 64, generator=g))
+    stats = {"eigvecs": q, "eigvals": torch.logspace(0, -2, 64), "mean": torch.randn(64, generator=g)}
+    cases = [
+        ("zca", dict(r=16, shrinkage=0.2, freeze_epochs=5), "ZCA16_fz5_s2", 64),  # low-rank ZCA still maps D -> D
+        ("zca", dict(freeze_epochs=-1, bias=False), "ZCA_fzperm_nobias", 64),
+        ("pca", dict(r=8), "PCA8_fz0", 8),
+        ("attention", dict(r=8, freeze_epochs=2), "Attn8_scaled_fz2", 8),
+        ("attention", dict(scale_by_eigvals=False), "AttnFull_fz0", 64),
+    ]
+    for kind, warm, tag, width in cases:
+        mod, out_dim, got = _build_preprocessor(kind, warm, stats)
+        assert (got, out_dim) == (tag, width), (kind, warm, got)
+    with pytest.raises(ValueError, match="Unknown preprocessor type"):
+        _build_preprocessor("whiten", {}, stats)
+    base = {"model": dict(task_type="reg", image_size=64, patch_size=8, hidden_size=32, num_hidden_layers=1,
+                          num_attention_heads=2, stride_size=8, proj_fn="SW"), "loss": {"name": "mae"}, "data": {"param": "a"}}
+    with pytest.raises(ValueError, match="cov_path"):
+        get_model({**base, "warmup": {"preprocessor": "zca"}})
+    path = tmp_path / "cov.pt"
+    torch.save(stats, path)
+    bad = {**base, "model": dict(base["model"], image_size=128), "warmup": {"preprocessor": "pca", "cov_path": str(path)}}
+    with pytest.raises(ValueError, match="Mismatch"):
+        get_model(bad)
+    cfg = {**base, "model": dict(base["model"]), "warmup": {"preprocessor": "pca", "cov_path": str(path), "r": 16}}
+    m = get_model(cfg)
+    assert m.name == "PCA16_fz0_ViT_p8_h32_l1_a2_s8_pSW" and cfg["model"]["image_size"] == 16 and m.config.image_size == 16
+    assert get_model(base).name == "ViT_p8_h32_l1_a2_s8_pSW"
+
+
+def test_checkpointer_keeps_best_and_last(tmp_path):
+    from vit_amd.trainer import Checkpointer, load_checkpoint_file, model_state_from_checkpoint
+
+    class T:  # the two attributes / one method the callback uses
+        rank, current_epoch = 0, 0
+
+        def make_checkpoint(self, module):
+            return {"epoch": self.current_epoch, "global_step": 0, "state_dict": {"model.w": torch.tensor([float(self.current_epoch)])},
+                    "callbacks": {}}
+
+    ck, t = Checkpointer(str(tmp_path), "val_mae", "min"), T()
+    for epoch, v in enumerate([0.5, 0.4, 0.45, 0.3]):
+        t.current_epoch = epoch
+        ck.after_validation(t, None, {"val_mae": v})
+        assert sorted(os.listdir(tmp_path)) == sorted({os.path.basename(ck.best_path), "last.ckpt"})
+    assert os.path.basename(ck.best_path) == "epoch=3-val_mae=0.3000.ckpt" and ck.best_score == 0.3
+    assert float(model_state_from_checkpoint(load_checkpoint_file(ck.resolve("best")))["w"]) == 3.0
+    t.current_epoch = 4
+    ck.after_validation(t, None, {"val_mae": 0.9})
+    assert os.path.basename(ck.best_path) == "epoch=3-val_mae=0.3000.ckpt"
+    assert float(model_state_from_checkpoint(load_checkpoint_file(ck.resolve("last")))["w"]) == 4.0
+    mx = Checkpointer(str(tmp_path / "m"), "val_acc", "max")
+    assert mx.better(0.1) and not (mx.__setattr__("best_score", 0.5) or mx.better(0.4)) and mx.better(0.6)

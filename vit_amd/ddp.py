@@ -17,7 +17,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-__all__ = ["GradAllReducer", "broadcast_parameters", "init_distributed", "shard_indices"]
+__all__ = ["GradAllReducer", "ShardedGradReducer", "make_reducer", "broadcast_parameters", "init_distributed",
+           "shard_indices"]
 
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -107,3 +108,72 @@ class GradAllReducer:
                 t.div_(self.world)
         self._pending = []
         self._seen = 0
+
+
+class ShardedGradReducer(GradAllReducer):
+    """SURVEY.md section 8e's second schedule ("zero1"): reduce-scatter the gradient buckets, run AdamW on the 1/world
+    shard each rank owns (1/world of the optimizer's 30 B/parameter HBM traffic), all-gather the updated fp32 parameters
+    (the bf16 shadow is re-cast locally).  Same bytes on the xGMI links as the all-reduce (reduce-scatter + all-gather IS a
+    ring all-reduce), but the all-gather half sits after the optimizer instead of overlapping backward, so this pays when the
+    optimizer pass is the larger cost; it is a switch (`train.ddp_exchange: zero1` / VIT_DDP_EXCHANGE), not the default.
+
+    A bucket is sharded when its length divides by 8 * world (shard starts stay 32-byte aligned); other buckets (the few
+    thousand tail / embedding elements of small configs) are all-reduced and updated redundantly on every rank.
+    The clipping norm = sum over the all-reduced buckets (identical everywhere) + all-reduce of the ranks' shard sums.
+    gloo has no reduce-scatter: there the bucket is all-reduced and the rank then simply uses its shard (same values)."""
+
+    def __init__(self, grads_getter, buckets, group=None, max_bucket_elems: int = 64 << 20):
+        super().__init__(grads_getter, buckets, group, max_bucket_elems)
+        self.mode = "zero1"
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.sharded = [(hi - lo) > 0 and (hi - lo) % (8 * self.world) == 0 for lo, hi in buckets]
+        self.calls_per_step = sum(1 for lo, hi in buckets if hi > lo)
+        self.gather_calls_per_step = sum(self.sharded)
+
+    def shard(self, lo: int, hi: int) -> Tuple[int, int]:
+        c = (hi - lo) // self.world
+        return lo + self.rank * c, lo + (self.rank + 1) * c
+
+    def is_sharded(self, lo: int, hi: int) -> bool:
+        return self.world > 1 and self.sharded[self.buckets.index((lo, hi))]
+
+    def bucket_ready(self, lo: int, hi: int):
+        if self.world <= 1 or hi <= lo:
+            return
+        if not self.is_sharded(lo, hi) or dist.get_backend(self.group) != "nccl":
+            return super().bucket_ready(lo, hi)
+        g = self._get()
+        a, b = self.shard(lo, hi)
+        w = dist.reduce_scatter_tensor(g[a:b], g[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        self._pending.append((w, None))
+        self.bytes_reduced += (hi - lo) * 4
+
+    def all_gather_params(self, flat: torch.Tensor):
+        """After the sharded update: every rank receives the other ranks' updated slices of the sharded buckets."""
+        if self.world <= 1:
+            return
+        works = []
+        for (lo, hi), sh in zip(self.buckets, self.sharded):
+            if not sh:
+                continue
+            a, b = self.shard(lo, hi)
+            if dist.get_backend(self.group) == "nccl":
+                works.append(dist.all_gather_into_tensor(flat[lo:hi], flat[a:b], group=self.group, async_op=True))
+            else:
+                if flat.is_cuda:
+                    torch.cuda.current_stream(flat.device).synchronize()
+                c = b - a
+                works.append(dist.all_gather([flat[lo + r * c:lo + (r + 1) * c] for r in range(self.world)], flat[a:b].clone(),
+                                             group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+
+def make_reducer(kind: str, engine, group=None):
+    """'allreduce' (default) or 'zero1' over the engine's flat gradient buffer and its backward-ordered buckets."""
+    kind = (kind or "allreduce").lower()
+    if kind in ("allreduce", "all_reduce", "ar"):
+        return GradAllReducer(lambda: engine.grads, engine.layout.buckets(), group)
+    if kind in ("zero1", "reduce_scatter", "rs"):
+        return ShardedGradReducer(lambda: engine.grads, engine.layout.buckets(), group)
+    raise ValueError(f"unknown train.ddp_exchange '{kind}' (use 'allreduce' or 'zero1')")

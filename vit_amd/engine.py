@@ -149,6 +149,7 @@ class ViTEngine:
         self.base_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self.step_counter = 0
         self._last = None
+        self._gen = 0  # bumped by every forward: the activation arena holds ONE forward, backward checks it is still that one
         self.grad_ready_cb: Optional[Callable[[int, int], None]] = None
         # Parameters are views of `flat` with their OWN version counters (nn.Parameter / .data re-pointing do not share
         # the base's), so "were the f32 weights modified since the bf16 shadow was made?" is answered by a signature
@@ -166,8 +167,8 @@ class ViTEngine:
         elif ps in ("bf16-mixed", "bf16", "bf16-true", "bfloat16"):
             mode = "bf16"
         elif ps in ("16-mixed", "16", "16-true", "fp16"):
-            print("[vit_amd] fp16 precision is not implemented on this path; using bf16-mixed arithmetic instead")
-            mode = "bf16"
+            raise ValueError(f"precision '{precision}': fp16 arithmetic is not implemented on this path (it would need loss "
+                             f"scaling); use '32' or 'bf16-mixed'")
         else:
             raise ValueError(f"Unsupported precision '{precision}'")
         if mode != self.precision:
@@ -317,6 +318,7 @@ class ViTEngine:
             raise VitError("pixel_values must live on the GPU")
         x = x.contiguous().to(torch.float32)
         B = x.shape[0]
+        self._gen += 1
         T, D, Fd, H, L, N, P, S = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
             c.num_hidden_layers, c.num_patches, c.patch_size, c.stride
         dh, M = c.head_dim, B * T
@@ -384,9 +386,17 @@ class ViTEngine:
             if labels.numel() != n_expected:
                 raise ValueError(f"labels has {labels.numel()} elements, expected {n_expected}")
         logits, loss = vf.head_loss_fwd(a["last"], self.p(hn + ".weight"), self.p(hn + ".bias"), labels, self.loss_kind)
-        self._last = dict(B=B, seed=seed, ph=ph, pa=pa, labels=labels, logits=logits)
+        self._last = dict(B=B, seed=seed, ph=ph, pa=pa, labels=labels, logits=logits, gen=self._gen, grad=need_grad)
         hs = [t.clone() for t in a["x"]] if output_hidden_states else None
         return loss, logits, hs, atts
+
+    def saved_attentions(self):
+        """Attention probabilities (before dropout) of every layer of the LAST need_grad forward, from its saved qkv."""
+        st, c = self._last, self.cfg
+        if st is None or not st["grad"] or st["gen"] != self._gen:
+            raise VitError("saved_attentions(): the last forward did not keep per-layer activations")
+        return [vf.attention_probs(self.act["qkv"][i], st["B"], c.num_attention_heads, c.seq_len, c.head_dim,
+                                   c.head_dim ** -0.5) for i in range(c.num_hidden_layers)]
 
     def _ln(self, x, name, out, mean, rstd):
         vf.layernorm_fwd(x, self.p(name + ".weight"), self.p(name + ".bias"), self.cfg.layer_norm_eps, out=out,
@@ -397,12 +407,17 @@ class ViTEngine:
                                   self.cfg.layer_norm_eps, out=out, mean=mean, rstd=rstd)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dloss: torch.Tensor, need_dx: bool = False):
+    def backward(self, dloss: torch.Tensor, need_dx: bool = False, gen: Optional[int] = None):
         """Fill self.grads (every trainable slice exactly once) for the last forward; calls grad_ready_cb(lo, hi) as
-        each bucket of the flat gradient buffer is complete (used to overlap the RCCL all-reduce)."""
+        each bucket of the flat gradient buffer is complete (used to overlap the RCCL all-reduce).  `gen`: the forward this
+        backward belongs to (ViTEngine._gen at that time); the arena holds one forward's activations, so a later forward
+        (a second loss term, an eval pass, a viz hook) makes them unavailable and that is an error, not a wrong gradient."""
         st = self._last
         if st is None or st["labels"] is None:
             raise VitError("backward without a preceding forward(labels=...)")
+        if not st["grad"] or (gen is not None and gen != st["gen"]) or st["gen"] != self._gen:
+            raise VitError("backward: the activations of that forward are gone -- another forward ran on this model in "
+                           "between (the engine keeps the activations of ONE forward; run backward before the next forward)")
         c = self.cfg
         a, t = self.act, self.tmp
         B, seed, ph, pa = st["B"], st["seed"], st["ph"], st["pa"]
@@ -421,10 +436,15 @@ class ViTEngine:
         dx, dx_other = t["dxa"], t["dxb"]
         # every LayerNorm backward below also emits dy = dropout_mask * dx (bf16) and its column sums: the gradient of
         # the Linear output underneath the next "dropout(.) + residual" going down, and that Linear's bias gradient
-        last_pre = f"vit.encoder.layer.{L - 1}."
-        vf.layernorm_bwd_fused(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
-                               a["rstdF"], None, dx, self.g("vit.layernorm.weight"), self.g("vit.layernorm.bias"),
-                               t["dy"], self.g(last_pre + "output.dense.bias"), (ph, seed, self._site(L - 1, 2)))
+        if L == 0:  # no encoder layer: the final LayerNorm sits directly on the embeddings
+            vf.layernorm_bwd(t["dlast"].view(M, D), a["x"][0].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
+                             a["rstdF"], dres=None, dx=dx, dgamma=self.g("vit.layernorm.weight"),
+                             dbeta=self.g("vit.layernorm.bias"))
+        else:
+            last_pre = f"vit.encoder.layer.{L - 1}."
+            vf.layernorm_bwd_fused(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
+                                   a["rstdF"], None, dx, self.g("vit.layernorm.weight"), self.g("vit.layernorm.bias"),
+                                   t["dy"], self.g(last_pre + "output.dense.bias"), (ph, seed, self._site(L - 1, 2)))
         if cb:
             cb(self.layout.tail_start, self.layout.n_trainable)
         for i in reversed(range(L)):

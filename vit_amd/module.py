@@ -1,22 +1,31 @@
-"""`ViTLModule` / `BaseLightningModule`: the module surface the reference's trainer calls (src/vit.py:58-215,
-src/basemodule.py:143-196), on top of the MI355X `MyViT`.
+"""`ViTLModule` / `BaseLightningModule`: the module surface the reference's trainer drives (src/vit.py:58-215,
+src/basemodule.py:143-196), over the MI355X `MyViT`.
 
-Same methods and step semantics: `forward(flux, labels, loss_only=True)`, `training_step` (optional on-the-fly noise:
-flux + randn_like(flux) * error * noise_level, vit.py:83-92), `_shared_eval_step` / `validation_step` / `test_step`
-with the 3- and 4-tuple batch contracts (spec_datasets.py:28-34), `configure_optimizers` (ReduceLROnPlateau guard and
-OneCycle step injection, basemodule.py:152-182), `self.log(...)` names (`{loss_name}_loss`, `val_mae`, `val_mse`,
-`val_r2`, `val_acc`, ...), `monitor_metric`.  When `lightning` is installed the classes subclass
-`lightning.LightningModule` and run under `L.Trainer` unchanged; otherwise a minimal stand-in base with the same
-`log` / `trainer` / `logger` attributes is used by vit_amd.trainer (Lightning is not part of this image).
+What is kept from the reference is the SURFACE: method names (`forward`, `training_step`, `validation_step`, `test_step`,
+`configure_optimizers`, the `on_*` hooks), attributes (`model`, `config`, `loss_name`, `monitor_metric`, `sweep`,
+`noise_level`, `task_type`, `val_dict` / `test_dict`), the batch contracts (3-tuple `(flux, error, labels)`; 4-tuple
+`(noisy, flux, error, labels)` from the eval datasets, spec_datasets.py:28-34) and the logged names
+(`{loss_name}_loss`, `{val|test}_{loss_name}_loss`, `*_mae`, `*_mse`, `*_r2`, `*_acc`, `val_bias_median`, `val_p90`,
+`val_beta`).  The bodies are this build's own:
+  * one model evaluation per eval batch (the reference runs the model a second time in validation_step / test_step only to
+    fetch predictions, vit.py:133-148, 204-212 -- same values in eval mode);
+  * epoch statistics (median bias, 90th percentile of |residual|, slope of the pred-vs-label line) in torch on the
+    collected predictions;
+  * metrics from vit_amd.metrics (torchmetrics is not in this image), whose DDP reduction sums states, not values;
+  * training noise through the `vit_add_noise` kernel.
+With `lightning` installed the classes subclass `lightning.LightningModule` and run under `L.Trainer`; otherwise a small
+stand-in base provides `log` / `trainer` / `logger` for vit_amd.trainer.
 """
 from __future__ import annotations
 
-from typing import Any, Dict
+import warnings
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from .builder import get_model
+from .metrics import Accuracy, MeanAbsoluteError, MeanSquaredError, R2Score
 from .optimizer import OptModule
 
 try:  # pragma: no cover - not installed in the build image
@@ -47,74 +56,14 @@ except Exception:  # noqa: BLE001
             pass
 
 
-def _normalize_task(config):
-    """vit.py:20-27"""
-    m = (config.get("model", {}) or {})
-    task = (m.get("task_type") or m.get("task") or "cls").lower()
-    return "cls" if task in ("classification", "cls", "class") else "reg"
+_CLS_ALIASES = frozenset({"classification", "cls", "class"})
 
 
-class _Mean:
-    """Running metric with torchmetrics' update/compute/reset shape (device-side sums, no host sync per step)."""
-
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.s = {}
-        self.n = 0
-
-    def _add(self, k, v):
-        self.s[k] = self.s.get(k, 0) + v
-
-
-class MeanAbsoluteError(_Mean):
-    def __call__(self, preds, target):
-        d = (preds.float().reshape(-1) - target.float().reshape(-1)).abs()
-        self._add("abs", d.sum())
-        self.n += d.numel()
-        return d.mean()
-
-    def compute(self):
-        return self.s["abs"] / self.n
-
-
-class MeanSquaredError(_Mean):
-    def __call__(self, preds, target):
-        d = (preds.float().reshape(-1) - target.float().reshape(-1)) ** 2
-        self._add("sq", d.sum())
-        self.n += d.numel()
-        return d.mean()
-
-    def compute(self):
-        return self.s["sq"] / self.n
-
-
-class R2Score(_Mean):
-    def __call__(self, preds, target):
-        p, t = preds.float().reshape(-1), target.float().reshape(-1)
-        self._add("st", t.sum()); self._add("stt", (t * t).sum()); self._add("res", ((t - p) ** 2).sum())
-        self.n += t.numel()
-        return self._r2(t.sum(), (t * t).sum(), ((t - p) ** 2).sum(), t.numel())
-
-    @staticmethod
-    def _r2(st, stt, res, n):
-        tot = stt - st * st / n
-        return 1 - res / tot
-
-    def compute(self):
-        return self._r2(self.s["st"], self.s["stt"], self.s["res"], self.n)
-
-
-class Accuracy(_Mean):
-    def __call__(self, logits, target):
-        c = (logits.argmax(-1) == target).float()
-        self._add("c", c.sum())
-        self.n += c.numel()
-        return c.mean()
-
-    def compute(self):
-        return self.s["c"] / self.n
+def _normalize_task(config) -> str:
+    """'cls' or 'reg' from model.task_type (legacy key model.task; default 'cls'): vit.py:20-27."""
+    model_cfg = config.get("model") or {}
+    raw = model_cfg.get("task_type") or model_cfg.get("task") or "cls"
+    return "cls" if str(raw).lower() in _CLS_ALIASES else "reg"
 
 
 class BaseLightningModule(_Base):
@@ -127,121 +76,131 @@ class BaseLightningModule(_Base):
         self.sweep = False
 
     def configure_optimizers(self):
-        """basemodule.py:152-182"""
-        opt_config = {**self.config.get("opt", {})}
-        opt_config["monitor_metric"] = getattr(self, "monitor_metric", self.loss_name)
-        lr_sch = opt_config.get("lr_sch", "").lower()
-        data_config = self.config.get("data", {})
-        has_val_path = bool(data_config.get("val_path"))
-        if "plateau" in lr_sch and not has_val_path:
-            print("[WARNING] ReduceLROnPlateau requires validation data ('data.val_path' in config) but none configured.")
-            print("[WARNING] Disabling learning rate scheduler. Consider adding validation data or using a different scheduler.")
-            opt_config.pop("lr_sch", None)
-        if "onecycle" in lr_sch:
-            train_config = self.config.get("train", {})
-            batch_size = train_config.get("batch_size", 64)
-            num_samples = data_config.get("num_samples", 32000)
-            epochs = train_config.get("ep", 100)
-            steps_per_epoch = (num_samples + batch_size - 1) // batch_size
-            opt_config["steps_per_epoch"] = steps_per_epoch
-            opt_config["epochs"] = epochs
-            print(f"[OneCycleLR] Calculated steps_per_epoch={steps_per_epoch}, epochs={epochs}")
-        return OptModule.from_config(opt_config)(self.model)
+        """Optimizer (+ scheduler) from the `opt` section (basemodule.py:152-182).  Two adjustments are made to that
+        section first: a plateau scheduler needs a validation metric, so without `data.val_path` it is dropped; a
+        one-cycle scheduler needs the run length, derived from data.num_samples / train.batch_size / train.ep."""
+        cfg = self.config
+        opt = dict(cfg.get("opt") or {})
+        opt["monitor_metric"] = getattr(self, "monitor_metric", self.loss_name)
+        schedule = str(opt.get("lr_sch") or "").lower()
+        data = cfg.get("data") or {}
+        if "plateau" in schedule and not data.get("val_path"):
+            warnings.warn("opt.lr_sch is a plateau scheduler but data.val_path is not set: there is no validation metric "
+                          "to monitor, so the run continues WITHOUT a learning-rate scheduler", stacklevel=2)
+            del opt["lr_sch"]
+        if "onecycle" in schedule:
+            train = cfg.get("train") or {}
+            per_step = int(train.get("batch_size", 64))
+            opt["steps_per_epoch"] = -(-int(data.get("num_samples", 32000)) // per_step)
+            opt["epochs"] = int(train.get("ep", 100))
+        return OptModule.from_config(opt)(self.model)
 
 
 class ViTLModule(BaseLightningModule):
     def __init__(self, model=None, config={}):
-        model = model or self.get_model(config)
-        super().__init__(model=model, config=config)
+        super().__init__(model=model or self.get_model(config), config=config)
         self.save_hyperparameters(ignore=["model"])
         self.task_type = _normalize_task(config)
-        self.noise_level = (config.get("noise", {}) or {}).get("noise_level", 0.0)
+        self.noise_level = (config.get("noise") or {}).get("noise_level", 0.0)
         if self.task_type == "cls":
             self.accuracy = Accuracy()
             self.monitor_metric = "acc"
+            self._metrics = {"acc": self.accuracy}
         else:
             self.mae, self.mse, self.r2 = MeanAbsoluteError(), MeanSquaredError(), R2Score()
             self.monitor_metric = "mae"
+            self._metrics = {"mae": self.mae, "mse": self.mse, "r2": self.r2}
 
     def get_model(self, config):
         return get_model(config)
 
+    def epoch_metrics(self) -> Dict[str, Any]:
+        """name -> running metric object (vit_amd.trainer resets / syncs / computes them per evaluation epoch)."""
+        return self._metrics
+
+    # ------------------------------------------------------------------ steps
     def forward(self, flux, labels, loss_only=True):
         outputs = self.model(flux, labels=labels)
         return outputs.loss if loss_only else outputs
 
+    def _augment(self, flux: torch.Tensor, error: torch.Tensor) -> torch.Tensor:
+        """Training-time noise (vit.py:86-88): flux + N(0,1) * error * noise_level, drawn on the device by `vit_add_noise`.
+        The per-step seed comes from torch's seeded CPU generator, so seed_everything(42) fixes the whole run."""
+        if not self.noise_level or self.noise_level <= 0:
+            return flux
+        from . import functional as vf
+
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return vf.add_noise(flux.contiguous().float(), error.contiguous().float(), float(self.noise_level), seed)
+
     def training_step(self, batch, batch_idx):
         flux, error, labels = batch
-        if self.noise_level > 0:
-            # vit.py:86-88; on the device through vit_add_noise (no arithmetic of the path runs in torch), one fresh
-            # seed per step drawn from torch's seeded CPU generator so that seed_everything(42) fixes the whole run
-            from . import functional as vf
-
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            noisy = vf.add_noise(flux.contiguous().float(), error.contiguous().float(), self.noise_level, seed)  # raises off-GPU
-            loss = self(noisy, labels, loss_only=True)
-        else:
-            loss = self(flux, labels, loss_only=True)
+        loss = self(self._augment(flux, error), labels, loss_only=True)
         self.log(f"{self.loss_name}_loss", loss, on_step=True, on_epoch=True, prog_bar=True)
         return loss
 
-    def _shared_eval_step(self, batch, prefix):
+    def _eval_inputs(self, batch) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(model input, labels) of an eval batch.  Eval datasets carry a fixed-seed noisy copy first (4-tuple); it is
+        used only when the run has noise switched on."""
+        labels = batch[-1]
         if len(batch) == 4:
-            noisy, flux, error, labels = batch
-            outputs = self.forward(noisy if self.noise_level > 0 else flux, labels, loss_only=False)
-        else:
-            flux, error, labels = batch
-            outputs = self.forward(flux, labels, loss_only=False)
-        loss = outputs.loss
-        self.log(f"{prefix}_{self.loss_name}_loss", loss, on_step=False, on_epoch=True)
-        if self.task_type == "cls":
-            acc = self.accuracy(outputs.logits, labels)
-            self.log(f"{prefix}_acc", acc, on_step=False, on_epoch=True, prog_bar=True)
-        else:
-            preds = outputs.logits.squeeze()
-            self.log(f"{prefix}_mae", self.mae(preds, labels), on_step=False, on_epoch=True)
-            self.log(f"{prefix}_mse", self.mse(preds, labels), on_step=False, on_epoch=True)
-            self.log(f"{prefix}_r2", self.r2(preds, labels), on_step=False, on_epoch=True)
-        self._last_eval_outputs = outputs
-        return loss
+            return (batch[0] if self.noise_level > 0 else batch[1]), labels
+        if len(batch) == 3:
+            return batch[0], labels
+        raise ValueError(f"eval batch must be (flux, error, labels) or (noisy, flux, error, labels); got {len(batch)} items")
+
+    def _shared_eval_step(self, batch, prefix):
+        x, labels = self._eval_inputs(batch)
+        outputs = self.forward(x, labels, loss_only=False)
+        self.log(f"{prefix}_{self.loss_name}_loss", outputs.loss, on_step=False, on_epoch=True)
+        scored = outputs.logits if self.task_type == "cls" else outputs.logits.squeeze()
+        for name, metric in self._metrics.items():
+            self.log(f"{prefix}_{name}", metric(scored, labels), on_step=False, on_epoch=True, prog_bar=(name == "acc"))
+        store: Optional[dict] = getattr(self, f"{prefix}_dict", None)
+        if self.task_type == "reg" and store is not None:
+            store["preds"].append(scored.detach().float().cpu())
+            store["labels"].append(labels.detach().float().cpu())
+        return outputs.loss
 
     def validation_step(self, batch, batch_idx):
-        loss = self._shared_eval_step(batch, "val")
-        if self.task_type == "reg" and hasattr(self, "val_dict"):
-            # the reference runs the model a second time here to fetch the predictions (vit.py:133-148); the values are
-            # identical in eval mode, so the outputs of the first pass are re-used
-            self.val_dict["preds"].append(self._last_eval_outputs.logits.squeeze().detach().cpu())
-            self.val_dict["labels"].append(batch[-1].detach().cpu())
-        return loss
+        return self._shared_eval_step(batch, "val")
 
+    def test_step(self, batch, batch_idx):
+        return self._shared_eval_step(batch, "test")
+
+    # ------------------------------------------------------------------ epoch-level regression statistics
     def on_validation_start(self):
         if self.task_type == "reg":
             self.val_dict = {"preds": [], "labels": []}
-
-    def on_validation_epoch_end(self):
-        """Epoch-level bias / p90 / slope (vit.py:157-187)."""
-        if self.task_type != "reg" or not hasattr(self, "val_dict") or not self.val_dict["preds"]:
-            return
-        import numpy as np
-
-        all_preds = torch.cat([p.reshape(p.shape[0], -1) if p.dim() > 0 else p.reshape(1, 1) for p in self.val_dict["preds"]], 0).numpy()
-        all_labels = torch.cat([l.reshape(l.shape[0], -1) for l in self.val_dict["labels"]], 0).numpy()
-        for i in range(all_preds.shape[1]):
-            residuals = all_preds[:, i] - all_labels[:, i]
-            coeffs = np.polyfit(all_labels[:, i], all_preds[:, i], 1)
-            suffix = "" if all_preds.shape[1] == 1 else f"_{i}"
-            self.log(f"val_bias_median{suffix}", float(np.median(residuals)), on_epoch=True)
-            self.log(f"val_p90{suffix}", float(np.percentile(np.abs(residuals), 90)), on_epoch=True)
-            self.log(f"val_beta{suffix}", float(coeffs[0]), on_epoch=True)
-        self.val_dict = {"preds": [], "labels": []}
 
     def on_test_start(self):
         if self.task_type == "reg":
             self.test_dict = {"preds": [], "labels": []}
 
-    def test_step(self, batch, batch_idx):
-        loss = self._shared_eval_step(batch, "test")
-        if self.task_type == "reg" and hasattr(self, "test_dict"):
-            self.test_dict["preds"].append(self._last_eval_outputs.logits.squeeze().detach().cpu())
-            self.test_dict["labels"].append(batch[-1].detach().cpu())
-        return loss
+    @staticmethod
+    def _residual_stats(pred: torch.Tensor, label: torch.Tensor) -> Dict[str, float]:
+        """Median of (pred - label), 90th percentile of |pred - label| (linear interpolation between order statistics)
+        and the least-squares slope of pred against label, in float64."""
+        p, t = pred.double(), label.double()
+        res = p - t
+        # torch.median returns the lower of the two middle values for an even count; the statistic wanted is their mean
+        bias = float(torch.quantile(res, 0.5))
+        p90 = float(torch.quantile(res.abs(), 0.9))
+        tc = t - t.mean()
+        denom = float((tc * tc).sum())
+        slope = float((tc * (p - p.mean())).sum() / denom) if denom > 0 else float("nan")
+        return {"bias_median": bias, "p90": p90, "beta": slope}
+
+    def on_validation_epoch_end(self):
+        """val_bias_median / val_p90 / val_beta per regression target (suffix _i when there are several): vit.py:157-187."""
+        store = getattr(self, "val_dict", None)
+        if self.task_type != "reg" or not store or not store["preds"]:
+            return
+        n_rows = sum(int(l.shape[0]) if l.dim() > 0 else 1 for l in store["labels"])
+        preds = torch.cat([p.reshape(-1) for p in store["preds"]]).reshape(n_rows, -1)
+        labels = torch.cat([l.reshape(-1) for l in store["labels"]]).reshape(n_rows, -1)
+        for col in range(preds.shape[1]):
+            tag = "" if preds.shape[1] == 1 else f"_{col}"
+            for key, value in self._residual_stats(preds[:, col], labels[:, col]).items():
+                self.log(f"val_{key}{tag}", value, on_epoch=True)
+        self.val_dict = {"preds": [], "labels": []}

@@ -18,12 +18,20 @@ __all__ = ["OptModule", "FusedAdamW"]
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    """AdamW over MyViT's flat buffers.  `step()` == torch.optim.AdamW.step() for every trainable parameter; the pooler
-    (no gradient in the reference either) is skipped like torch skips grad-less parameters.
+    """AdamW over MyViT's flat buffers.  `step()` == torch.optim.AdamW.step(): parameters without a gradient (frozen ones,
+    the never-used pooler, everything when no backward ran) are left alone together with their moments, exactly as torch
+    skips them; `state_dict()` / `load_state_dict()` speak torch.optim.AdamW's format (per-parameter `step`, `exp_avg`,
+    `exp_avg_sq`, indexed in `model.parameters()` order), so optimizer state moves between this class and the reference's
+    torch optimizer through a Lightning checkpoint.
 
     Gradient clipping: either the caller clips `.grad` beforehand (Lightning's gradient_clip_val path; the grads are
-    views of the flat buffer, so that is seen here), or `set_grad_clip(max_norm)` fuses
-    clip_grad_norm_(max_norm) into the step (norm kernel + coefficient applied on the fly)."""
+    views of the flat buffer, so that is seen here), or `set_grad_clip(max_norm)` fuses clip_grad_norm_(max_norm) into the
+    step (norm kernel + coefficient applied on the fly).
+
+    Under data parallelism (`attach_reducer`) the flat gradient buffer holds the rank-averaged gradient when `step()` runs;
+    a `.grad` that is NOT the flat-buffer view (a hook or an accumulation replaced it) would silently overwrite that
+    average with a local gradient, so it is an error there.  With a sharding reducer ('zero1') each rank updates only its
+    shard of every sharded bucket and the updated parameters are all-gathered."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, adam_l2: bool = False):
         self.model = model
@@ -40,18 +48,53 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._clip: Optional[float] = None
         self._sq = None
+        self._reducer = None
         self.last_grad_norm: Optional[torch.Tensor] = None
 
     def set_grad_clip(self, max_norm: Optional[float]):
         self._clip = max_norm
 
+    def attach_reducer(self, reducer):
+        self._reducer = reducer
+
     def _ensure_state(self):
         eng = self.model.engine
         eng._ensure_device_state()
         if self._m is None or self._m.device != eng.flat.device:
-            self._m = torch.zeros_like(eng.flat)
-            self._v = torch.zeros_like(eng.flat)
+            m = torch.zeros_like(eng.flat)
+            v = torch.zeros_like(eng.flat)
+            if self._m is not None:  # state loaded before the model moved to the GPU
+                m.copy_(self._m)
+                v.copy_(self._v)
+            self._m, self._v = m, v
             self._sq = torch.zeros(1, dtype=torch.float32, device=eng.flat.device)
+
+    def _active_ranges(self):
+        """Contiguous [lo, hi) runs of the flat buffer whose parameters have a gradient this step; also folds a replaced
+        `.grad` back into the flat gradient buffer (single process only)."""
+        eng, lay = self.model.engine, self.model.engine.layout
+        spans = []
+        for name, p in zip(self.model._param_names, self.model._param_list):
+            off, _ = lay.entries[name]
+            if off >= lay.n_trainable or p.grad is None:
+                continue
+            gv = eng.g(name)
+            if p.grad.data_ptr() != gv.data_ptr():
+                if self._reducer is not None:
+                    raise RuntimeError(f"{name}.grad is not the flat gradient buffer's view (a hook or an accumulation into "
+                                       f"an existing .grad replaced it): under data parallelism that would overwrite the "
+                                       f"rank-averaged gradient with a local one")
+                gv.copy_(p.grad)
+            # the alignment pad behind an entry belongs to it (zeros in every buffer, never read back)
+            spans.append((off, off + (lay.numel(name) + 7) // 8 * 8))
+        spans.sort()
+        runs = []
+        for a, b in spans:
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        return [(a, b) for a, b in runs]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -62,51 +105,123 @@ class FusedAdamW(torch.optim.Optimizer):
         eng = self.model.engine
         self._ensure_state()
         g = self.param_groups[0]
-        n = eng.layout.n_trainable
-        self._step += 1
-        # .grad normally IS a view of the flat gradient buffer (autograd keeps the tensor our backward returned); if
-        # something replaced it (gradient accumulation into an existing .grad, a hook), copy it back first.
-        for name, p in zip(self.model._param_names, self.model._param_list):
-            if p.grad is not None:
-                gv = eng.g(name)
-                if p.grad.data_ptr() != gv.data_ptr():
-                    gv.copy_(p.grad)
-        sq = None
+        runs = self._active_ranges()
         extras = [p for p in self._extras if p.grad is not None]
+        if not runs and not extras:
+            return loss  # nothing has a gradient: torch.optim would not touch anything either
+        self._step += 1
+        red = self._reducer if (self._reducer is not None and getattr(self._reducer, "mode", "") == "zero1") else None
+        if red is not None:
+            runs = self._shard_runs(runs, red)
+        sq = None
         if self._clip is not None:
-            sq = vf.grad_sqnorm(eng.grads[:n], out=self._sq)
+            sq = self._sq
+            first = True
+            for a, b in (runs if red is None else self._norm_runs_local):
+                vf.grad_sqnorm(eng.grads[a:b], out=sq, accumulate=not first)
+                first = False
+            if first:
+                sq.zero_()
+            if red is not None:  # shard sums -> global; the all-reduced buckets are added once (identical on every rank)
+                torch.distributed.all_reduce(sq)
+                for a, b in self._norm_runs_shared:
+                    vf.grad_sqnorm(eng.grads[a:b], out=sq, accumulate=True)
             for p in extras:
-                vf.grad_sqnorm(p.grad.contiguous().view(-1), out=self._sq, accumulate=True)
+                vf.grad_sqnorm(p.grad.contiguous().view(-1), out=sq, accumulate=True)
             self.last_grad_norm = sq
         shadow = eng.shadow if eng.precision == "bf16" else None  # f32 mode has no bf16 copy to refresh
-        vf.adamw_step(eng.flat, eng.grads, self._m, self._v, shadow, lr=float(g["lr"]), beta1=g["betas"][0],
-                      beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], step=self._step, sqnorm=sq,
-                      max_norm=float(self._clip or 0.0), n=n)
+        kw = dict(lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                  step=self._step, sqnorm=sq, max_norm=float(self._clip or 0.0))
+        for a, b in runs:
+            vf.adamw_step(eng.flat[a:b], eng.grads[a:b], self._m[a:b], self._v[a:b], None if shadow is None else shadow[a:b],
+                          **kw)
+        if red is not None:
+            red.all_gather_params(eng.flat)
+            if shadow is not None:
+                vf.cast_f32_bf16(eng.flat, shadow)
         eng.mark_shadow_fresh()  # the kernel rewrote flat AND shadow through raw pointers
         for p in extras:
             st = self._extra_state.get(id(p))
             if st is None or st[0].device != p.device:
                 st = self._extra_state[id(p)] = (torch.zeros_like(p.data).view(-1), torch.zeros_like(p.data).view(-1))
-            vf.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st[0], st[1], None, lr=float(g["lr"]),
-                          beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
-                          step=self._step, sqnorm=sq, max_norm=float(self._clip or 0.0))
+            vf.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), st[0], st[1], None, **kw)
         return loss
+
+    def _shard_runs(self, runs, red):
+        """Intersect the active runs with what this rank updates under 'zero1': its shard of every sharded bucket, the whole
+        of every all-reduced bucket.  Also records which pieces enter the norm locally (shards) / as shared (the rest)."""
+        own, local, shared = [], [], []
+        for (lo, hi), sh in zip(red.buckets, red.sharded):
+            a, b = red.shard(lo, hi) if sh else (lo, hi)
+            for ra, rb in runs:
+                x, y = max(a, ra), min(b, rb)
+                if x < y:
+                    own.append((x, y))
+                    (local if sh else shared).append((x, y))
+        self._norm_runs_local, self._norm_runs_shared = local, shared
+        return own
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=True)
 
+    # ------------------------------------------------------------------ torch.optim.AdamW-format state
     def state_dict(self):
-        return {"step": self._step, "m": self._m, "v": self._v,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        lay = self.model.engine.layout
+        index = {id(p): i for i, p in enumerate(self.param_groups[0]["params"])}
+        state = {}
+        if self._m is not None and self._step > 0:
+            for name, p in zip(self.model._param_names, self.model._param_list):
+                off, shape = lay.entries[name]
+                if off >= lay.n_trainable:
+                    continue
+                n = lay.numel(name)
+                state[index[id(p)]] = {"step": torch.tensor(float(self._step)),
+                                       "exp_avg": self._m[off:off + n].detach().cpu().clone().view(shape),
+                                       "exp_avg_sq": self._v[off:off + n].detach().cpu().clone().view(shape)}
+            for p in self._extras:
+                st = self._extra_state.get(id(p))
+                if st is not None:
+                    state[index[id(p)]] = {"step": torch.tensor(float(self._step)),
+                                           "exp_avg": st[0].detach().cpu().clone().view(p.shape),
+                                           "exp_avg_sq": st[1].detach().cpu().clone().view(p.shape)}
+        groups = []
+        for grp in self.param_groups:
+            d = {k: (list(v) if isinstance(v, tuple) else v) for k, v in grp.items() if k != "params"}
+            d["params"] = list(range(len(grp["params"])))
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._step = int(sd["step"])
-        self._ensure_state()
-        if sd.get("m") is not None:
-            self._m.copy_(sd["m"])
-            self._v.copy_(sd["v"])
-        for g, s in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update(s)
+        if "state" not in sd:  # round-1 layout: flat moment buffers
+            self._step = int(sd["step"])
+            if sd.get("m") is not None:
+                self._m, self._v = sd["m"].detach().clone().float(), sd["v"].detach().clone().float()
+            for grp, src in zip(self.param_groups, sd.get("param_groups", [])):
+                grp.update({k: v for k, v in src.items() if k != "params"})
+            return
+        lay = self.model.engine.layout
+        flat = self.model.engine.flat
+        if self._m is None or self._m.device != flat.device:
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        params = self.param_groups[0]["params"]
+        names = {id(p): n for n, p in zip(self.model._param_names, self.model._param_list)}
+        step = 0
+        for idx, st in sd["state"].items():
+            p = params[int(idx)]
+            step = max(step, int(float(st["step"])))
+            if id(p) in names:
+                off, _ = lay.entries[names[id(p)]]
+                n = lay.numel(names[id(p)])
+                self._m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self._v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            else:
+                self._extra_state[id(p)] = (st["exp_avg"].detach().clone().to(p.device).float().view(-1),
+                                            st["exp_avg_sq"].detach().clone().to(p.device).float().view(-1))
+        self._step = step
+        for grp, src in zip(self.param_groups, sd.get("param_groups", [])):
+            for k, v in src.items():
+                if k != "params":
+                    grp[k] = tuple(v) if k == "betas" else v
 
 
 class OptModule:

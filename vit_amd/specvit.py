@@ -74,6 +74,7 @@ class _ViTFunction(torch.autograd.Function):
         eng = model.engine
         loss, logits, _, _ = eng.forward(x, labels, training=training, need_grad=True)
         ctx.model = model
+        ctx.gen = eng._gen
         ctx.need_dx = bool(x.requires_grad)  # a trainable input preprocessor in front of the ViT
         ctx.mark_non_differentiable(logits)
         return loss, logits
@@ -82,7 +83,7 @@ class _ViTFunction(torch.autograd.Function):
     def backward(ctx, dloss, _dlogits):
         model = ctx.model
         eng = model.engine
-        dx = eng.backward(dloss, need_dx=ctx.need_dx)
+        dx = eng.backward(dloss, need_dx=ctx.need_dx, gen=ctx.gen)
         grads = []
         for name, p in zip(model._param_names, model._param_list):
             if not p.requires_grad or name.startswith("vit.pooler."):
@@ -108,7 +109,6 @@ class MyViT(nn.Module):
         self.engine = ViTEngine(config, loss_name=loss_name)
         self._loss_name = self.engine.loss_name
         self._model_name = build_model_name(config, model_name, full_config=full_config)
-        print(f"Creating {self._model_name} model with {self._loss_name} loss")  # basemodule.py:123
         self._build_tree()
         self.init_weights()
 
@@ -185,9 +185,12 @@ class MyViT(nn.Module):
         if self.preprocessor is not None:
             pixel_values = self.preprocessor(pixel_values)
         want_grad = torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self._param_list)
-        if want_grad and not (output_attentions or output_hidden_states):
+        if want_grad:
+            # the loss stays differentiable whatever else is asked for (as in the reference); hidden states / attention maps
+            # are read back from the activations that forward kept (maps: the probabilities before dropout)
             loss, logits = _ViTFunction.apply(self, pixel_values, labels, training, *self._param_list)
-            hs = atts = None
+            hs = [t.clone() for t in eng.act["x"]] if output_hidden_states else None
+            atts = eng.saved_attentions() if output_attentions else None
         else:
             with torch.no_grad():
                 loss, logits, hs, atts = eng.forward(pixel_values, labels, training=training, need_grad=False,

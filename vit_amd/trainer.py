@@ -1,18 +1,31 @@
-"""Minimal trainer reproducing the step semantics the reference obtains from `BaseTrainer(L.Trainer)` /
-`SpecTrainer` (src/basemodule.py:203-251, src/vit.py:349-435) -- Lightning itself is not part of this image:
+"""The training loop of the path, with the policy the reference gets from `BaseTrainer(L.Trainer)` / `SpecTrainer`
+(src/basemodule.py:203-251, src/vit.py:349-435, 455-465) -- Lightning itself is not part of this image.
 
-  seed (scripts/run.py:27-30) -> for epoch: for batch: zero_grad -> training_step (fwd) -> backward (DDP all-reduce
-  of the flat gradient buffer overlapped with it when devices > 1: hardware_utils.py:95) -> clip global grad-norm to
-  `train.grad_clip` or 0.5 (basemodule.py:244) -> optimizer.step();  validation every epoch (basemodule.py:249);
-  ReduceLROnPlateau on `val_{monitor}` / epoch- or step-interval schedulers (opt/optimizer.py:150-172);
-  EarlyStopping(patience 500, vit.py:365,417-424); `fast_dev_run` when `train.debug` (basemodule.py:245).
+  fit:   for epoch: [unfreeze the input preprocessor when its warm-up ends, prepca/callbacks.py:31-46]
+           for batch: zero_grad -> training_step (forward) -> backward (when devices > 1 the flat gradient buffer is
+                      mean-all-reduced bucket by bucket while backward runs: hardware_utils.py:95 'ddp')
+                      -> clip the global gradient norm to `train.grad_clip` or 0.5 (basemodule.py:244) -> optimizer step
+           validate every epoch (basemodule.py:249)
+           scheduler: ReduceLROnPlateau on `val_{monitor}` / per-epoch / per-step (opt/optimizer.py:150-172)
+           ModelCheckpoint(save_top_k=1, monitor=val_{mae|acc}, save_last=True) when `train.save` (vit.py:386-414)
+           EarlyStopping(monitor, patience 500 | 100 in a sweep, mode) (vit.py:365, 417-424)
+         `fast_dev_run` (one batch of everything, nothing saved) when `train.debug` (basemodule.py:245)
+         `fit(..., ckpt_path=)` resumes weights, optimizer state, scheduler state, epoch and step (vit.py:464)
+  test:  evaluation only, optionally from a checkpoint path or 'best' / 'last' (scripts/test.py:26-48)
+
+Logged scalars follow Lightning's `self.log(value, on_epoch=True)` reduction: the epoch value is the batch-size-weighted
+mean of the per-batch values.  That makes `val_mae` / `val_mse` the exact epoch MAE / MSE, and `val_r2` the weighted mean of
+the per-batch R^2 (what the reference logs: it passes the metric's batch VALUE to `self.log`, vit.py:113-121).  The metric
+objects' own epoch totals (`compute()` over everything seen) are kept in `Trainer.metric_totals`.  Under DDP both kinds are
+reduced from summed STATE (weighted sums and weights; metric sums and counts) so every rank monitors the same number --
+the reference logs without `sync_dist`, i.e. rank-local values, which would let ranks disagree about early stopping.
 
 'train.precision': '32' (default, as in the reference) -> fp32-class kernels (split-bf16 x3 GEMMs, fp32 attention);
 'bf16-mixed' -> bf16 MFMA operands with fp32 master weights / residual stream / statistics (the throughput path).
 """
 from __future__ import annotations
 
-import math
+import os
 import time
 from typing import Any, Dict, Iterable, Optional
 
@@ -21,7 +34,7 @@ import torch
 from . import ddp as ddp_mod
 from .optimizer import FusedAdamW
 
-__all__ = ["Trainer", "select_accelerator_and_devices", "get_training_strategy", "seed_everything"]
+__all__ = ["Trainer", "Checkpointer", "select_accelerator_and_devices", "get_training_strategy", "seed_everything"]
 
 
 def select_accelerator_and_devices(num_gpus: Optional[int] = None):
@@ -51,45 +64,131 @@ def _to_device(batch, device):
     return tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
 
 
+def _batch_size(batch) -> int:
+    for t in batch:
+        if torch.is_tensor(t) and t.dim() > 0:
+            return int(t.shape[0])
+    return 1
+
+
+class Checkpointer:
+    """ModelCheckpoint(save_top_k=1, monitor, mode, save_last=True): after each validation, `last.ckpt` is rewritten and,
+    when the monitored value improved, `epoch={e}-{monitor}={v:.4f}.ckpt` replaces the previous best file."""
+
+    def __init__(self, dirpath: str, monitor: str, mode: str):
+        self.dirpath, self.monitor, self.mode = dirpath, monitor, mode
+        self.best_score: Optional[float] = None
+        self.best_path: Optional[str] = None
+        self.last_path: Optional[str] = None
+
+    def better(self, v: float) -> bool:
+        if self.best_score is None:
+            return True
+        return v > self.best_score if self.mode == "max" else v < self.best_score
+
+    def after_validation(self, trainer: "Trainer", module, logs: Dict[str, float]):
+        if trainer.rank != 0:
+            return
+        os.makedirs(self.dirpath, exist_ok=True)
+        ckpt = trainer.make_checkpoint(module)
+        v = logs.get(self.monitor)
+        if v is not None and self.better(v):
+            path = os.path.join(self.dirpath, f"epoch={trainer.current_epoch}-{self.monitor}={v:.4f}.ckpt")
+            ckpt["callbacks"]["checkpoint"] = {"best_model_score": float(v), "best_model_path": path, "monitor": self.monitor}
+            torch.save(ckpt, path)
+            if self.best_path and self.best_path != path and os.path.exists(self.best_path):
+                os.remove(self.best_path)
+            self.best_score, self.best_path = float(v), path
+        ckpt["callbacks"]["checkpoint"] = {"best_model_score": self.best_score, "best_model_path": self.best_path or "",
+                                           "monitor": self.monitor}
+        self.last_path = os.path.join(self.dirpath, "last.ckpt")
+        torch.save(ckpt, self.last_path)
+
+    def resolve(self, which: str) -> str:
+        path = {"best": self.best_path, "last": self.last_path}.get(which, which)
+        if not path and which in ("best", "last"):
+            cand = os.path.join(self.dirpath, "last.ckpt")
+            if which == "last" and os.path.exists(cand):
+                return cand
+            raise FileNotFoundError(f"no '{which}' checkpoint has been written under {self.dirpath}")
+        return path
+
+
+def load_checkpoint_file(path: str) -> Dict[str, Any]:
+    """Checkpoints are read with a loader that executes nothing from the file."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    if "state_dict" not in ckpt:  # a bare state_dict (e.g. one written by round 1's --save)
+        ckpt = {"state_dict": ckpt}
+    return ckpt
+
+
+def model_state_from_checkpoint(ckpt: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+    """Lightning stores the LightningModule's state_dict: the network's tensors sit under the `model.` prefix."""
+    sd = ckpt["state_dict"]
+    return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+
+
 class Trainer:
-    def __init__(self, config: Dict[str, Any], device: Optional[torch.device] = None, verbose: bool = True):
+    def __init__(self, config: Dict[str, Any], device: Optional[torch.device] = None, verbose: bool = True,
+                 sweep: bool = False):
         """`config` is the `train` section (as the reference passes it: vit.py:359)."""
         self.max_epochs = config.get("ep", 10)
         self.gradient_clip_val = config.get("grad_clip", 0.5)
         self.fast_dev_run = bool(config.get("debug", False))
         self.precision = str(config.get("precision", "32"))
-        self.patience = int(config.get("patience", 500))
+        self.patience = int(config.get("patience", 100 if sweep else 500))
+        self.save_enabled = bool(config.get("save", False))
         self.rank, self.local_rank, self.world = ddp_mod.init_distributed()
         self.acc, self.device0 = select_accelerator_and_devices(config.get("gpus"))
         self.strategy = get_training_strategy(self.world)
         self.device = device or torch.device("cuda", self.local_rank)
         self.backend = torch.distributed.get_backend() if self.world > 1 else None
+        self.exchange = str(config.get("ddp_exchange", os.environ.get("VIT_DDP_EXCHANGE", "allreduce")))
         self.verbose = verbose and self.rank == 0
         self.logged: Dict[str, float] = {}
-        self._epoch_acc: Dict[str, list] = {}
+        self.metric_totals: Dict[str, float] = {}
+        self._acc: Dict[str, list] = {}
+        self._cur_bs = 1
         self.global_step = 0
         self.current_epoch = 0
         self.should_stop = False
         self.history = []
+        self.checkpointer: Optional[Checkpointer] = None
+        self.optimizer = None
+        self.sched_cfg = None
+        self.reducer = None
+        self._ready_for = None
 
-    # LightningModule.log lands here
+    # ------------------------------------------------------------------ logging (LightningModule.log lands here)
     def _log(self, name, value, on_step=None, on_epoch=None):
-        self._epoch_acc.setdefault(name, []).append(value.detach() if torch.is_tensor(value) else value)
+        v = value.detach().to(torch.float64).reshape(()) if torch.is_tensor(value) else torch.tensor(float(value), dtype=torch.float64)
+        slot = self._acc.setdefault(name, [None, 0.0])
+        w = float(self._cur_bs)
+        slot[0] = v * w if slot[0] is None else slot[0] + v.to(slot[0].device) * w
+        slot[1] += w
 
-    def _flush_epoch_logs(self):
-        out = {}
-        for k, vals in self._epoch_acc.items():
-            ts = [v.float().reshape(()) if torch.is_tensor(v) else torch.tensor(float(v)) for v in vals]
-            dev = next((t.device for t in ts if t.is_cuda), torch.device("cpu"))
-            out[k] = float(torch.stack([t.to(dev) for t in ts]).mean())
-        self._epoch_acc = {}
-        return out
+    def _flush_epoch_logs(self) -> Dict[str, float]:
+        names = sorted(self._acc)
+        if not names:
+            return {}
+        sums = torch.stack([self._acc[n][0].to(self.device if self.device.type == "cuda" and torch.cuda.is_available() else "cpu")
+                            for n in names])
+        wts = torch.tensor([self._acc[n][1] for n in names], dtype=torch.float64, device=sums.device)
+        if self.world > 1:  # every rank logs the same names in the same order (same step functions)
+            both = torch.stack([sums, wts])
+            torch.distributed.all_reduce(both)
+            sums, wts = both[0], both[1]
+        self._acc = {}
+        return {n: float(s / w) for n, s, w in zip(names, sums, wts)}
 
-    def _setup(self, module):
+    # ------------------------------------------------------------------ setup
+    def _setup(self, module, for_training: bool = True):
         module.trainer = self
         module.to(self.device)
         if hasattr(module.model, "set_precision"):
             module.model.set_precision(self.precision)  # basemodule.py:233: precision=str(train.precision or '32')
+        if not for_training or self._ready_for is module:
+            return
         conf = module.configure_optimizers()
         if isinstance(conf, dict):
             self.optimizer = conf["optimizer"]
@@ -103,22 +202,31 @@ class Trainer:
             eng._ensure_device_state()
             ddp_mod.broadcast_parameters(eng.flat)
             eng._shadow_version = -1
-            self.reducer = ddp_mod.GradAllReducer(lambda: eng.grads, eng.layout.buckets())
+            self.reducer = ddp_mod.make_reducer(self.exchange, eng)
             eng.grad_ready_cb = self.reducer.bucket_ready
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.set_grad_clip(self.gradient_clip_val)
-        # PreprocessorFreezeCallback (src/prepca/callbacks.py): warmup.freeze_epochs > 0 freezes the input preprocessor for
+            self.optimizer.attach_reducer(self.reducer)
+        # freeze schedule of the input preprocessor (src/prepca/callbacks.py): warmup.freeze_epochs > 0 freezes it for
         # that many epochs, -1 for good, 0 never.  (As in the reference, the optimizer was built from the parameters that
-        # existed at configure time: a preprocessor unfrozen later becomes trainable for autograd but is only stepped if
-        # the optimizer is rebuilt.)
-        warm = (getattr(module, "config", {}) or {}).get("warmup", {}) or {}
+        # existed at configure time: a preprocessor unfrozen later becomes trainable for autograd but is only stepped if it
+        # already was among the optimizer's parameters.)
+        warm = (getattr(module, "config", {}) or {}).get("warmup") or {}
         self.freeze_epochs = int(warm.get("freeze_epochs", 0) or 0)
         self._unfrozen = False
         if self.freeze_epochs != 0 and hasattr(module.model, "set_preprocessor_trainable"):
             module.model.set_preprocessor_trainable(False)
+        mon = getattr(module, "monitor_metric", "loss")
+        self.monitor = f"val_{mon}"
+        self.monitor_mode = "max" if mon == "acc" else "min"
+        if self.save_enabled and not self.fast_dev_run:
+            self.checkpointer = Checkpointer(os.environ.get("CKPT_DIR", "./checkpoints"), self.monitor, self.monitor_mode)
+        self._ready_for = module
 
+    # ------------------------------------------------------------------ one optimisation step
     def training_step(self, module, batch, batch_idx):
-        """One optimisation step with the reference's ordering."""
+        """zero_grad -> forward -> backward (+ overlapped gradient exchange) -> clip -> optimizer step."""
+        self._cur_bs = _batch_size(batch)
         self.optimizer.zero_grad(set_to_none=True)
         loss = module.training_step(batch, batch_idx)
         loss.backward()
@@ -136,87 +244,150 @@ class Trainer:
         self.global_step += 1
         return loss
 
+    # ------------------------------------------------------------------ evaluation
     @torch.no_grad()
     def validate(self, module, loader, prefix="val"):
+        was_training = module.training
         module.eval()
-        for m in ("mae", "mse", "r2", "accuracy"):
-            if hasattr(module, m):
-                getattr(module, m).reset()
-        hook = getattr(module, f"on_{'validation' if prefix == 'val' else 'test'}_start", None)
+        metrics = module.epoch_metrics() if hasattr(module, "epoch_metrics") else {}
+        for m in metrics.values():
+            m.reset()
+        stage = "validation" if prefix == "val" else "test"
+        hook = getattr(module, f"on_{stage}_start", None)
         if hook:
             hook()
         step = module.validation_step if prefix == "val" else module.test_step
         for i, batch in enumerate(loader):
-            step(_to_device(batch, self.device), i)
+            batch = _to_device(batch, self.device)
+            self._cur_bs = _batch_size(batch)
+            step(batch, i)
             if self.fast_dev_run:
                 break
-        hook = getattr(module, f"on_{'validation' if prefix == 'val' else 'test'}_epoch_end", None)
+        self._cur_bs = 1
+        hook = getattr(module, f"on_{stage}_epoch_end", None)
         if hook:
             hook()
         logs = self._flush_epoch_logs()
-        # torchmetrics semantics: epoch value = compute() over the whole epoch, not the mean of batch values
-        for name, attr in (("mae", "mae"), ("mse", "mse"), ("r2", "r2"), ("acc", "accuracy")):
-            if hasattr(module, attr) and getattr(module, attr).n:
-                logs[f"{prefix}_{name}"] = float(getattr(module, attr).compute())
-        if self.world > 1:
-            keys = sorted(logs)
-            t = torch.tensor([logs[k] for k in keys], dtype=torch.float64, device=self.device)
-            torch.distributed.all_reduce(t)
-            logs = {k: float(v) / self.world for k, v in zip(keys, t)}
+        for name, m in metrics.items():
+            if m.n:
+                m.sync()  # DDP: sum the metric STATE over ranks, then compute
+                self.metric_totals[f"{prefix}_{name}"] = float(m.compute())
         self.logged.update(logs)
+        if was_training:
+            module.train()
         return logs
 
-    def fit(self, module, train_loader: Iterable, val_loader: Optional[Iterable] = None):
+    def test(self, module, loader, ckpt_path: Optional[str] = None):
+        """Evaluation only (scripts/test.py:26-48): no optimizer is built, no parameter changes."""
+        if ckpt_path not in (None, "", "none", "None"):
+            path = self.checkpointer.resolve(ckpt_path) if self.checkpointer else ckpt_path
+            module.model.load_state_dict(model_state_from_checkpoint(load_checkpoint_file(path)))
+        self._setup(module, for_training=False)
+        return self.validate(module, loader, "test")
+
+    # ------------------------------------------------------------------ checkpoints
+    def make_checkpoint(self, module) -> Dict[str, Any]:
+        """Lightning's checkpoint layout (the keys the reference's `trainer.fit(ckpt_path=)` / `test(ckpt_path=)` read)."""
+        sd = {f"model.{k}": v.detach().cpu().clone() for k, v in module.model.state_dict().items()}
+        sch = self.sched_cfg["scheduler"].state_dict() if self.sched_cfg else None
+        return {
+            "epoch": int(self.current_epoch), "global_step": int(self.global_step), "state_dict": sd,
+            "optimizer_states": [self.optimizer.state_dict()] if self.optimizer is not None else [],
+            "lr_schedulers": [_plain(sch)] if sch is not None else [],
+            "callbacks": {"early_stopping": {"best_score": self._es_best, "wait_count": int(self._es_bad)}},
+            "hyper_parameters": {"config": _plain(getattr(module, "config", {}))},
+            # position of the dropout stream (seed, steps drawn): a resumed run continues the same mask sequence
+            "vit_amd": {"version": 2, "dropout_base_seed": int(module.model.engine.base_seed),
+                        "dropout_step": int(module.model.engine.step_counter)},
+        }
+
+    def _resume(self, module, ckpt_path: str) -> int:
+        ckpt = load_checkpoint_file(ckpt_path)
+        module.model.load_state_dict(model_state_from_checkpoint(ckpt))
+        if ckpt.get("optimizer_states"):
+            self.optimizer.load_state_dict(ckpt["optimizer_states"][0])
+        if ckpt.get("lr_schedulers") and self.sched_cfg:
+            self.sched_cfg["scheduler"].load_state_dict(ckpt["lr_schedulers"][0])
+        es = (ckpt.get("callbacks") or {}).get("early_stopping") or {}
+        self._es_best, self._es_bad = es.get("best_score"), int(es.get("wait_count", 0))
+        ck = (ckpt.get("callbacks") or {}).get("checkpoint") or {}
+        if self.checkpointer and ck.get("best_model_score") is not None:
+            self.checkpointer.best_score, self.checkpointer.best_path = ck["best_model_score"], ck.get("best_model_path") or None
+        own = ckpt.get("vit_amd") or {}
+        if "dropout_step" in own:
+            module.model.engine.base_seed = int(own["dropout_base_seed"])
+            module.model.engine.step_counter = int(own["dropout_step"])
+        self.global_step = int(ckpt.get("global_step", 0))
+        return int(ckpt["epoch"]) + 1 if "epoch" in ckpt else 0  # saved at the END of that epoch
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, module, train_loader: Iterable, val_loader: Optional[Iterable] = None, ckpt_path: Optional[str] = None):
+        self._es_best, self._es_bad = None, 0
         self._setup(module)
-        best, bad = None, 0
-        monitor = f"val_{getattr(module, 'monitor_metric', 'loss')}"
-        mode_max = monitor.endswith("acc")
+        first_epoch = self._resume(module, ckpt_path) if ckpt_path else 0
         epochs = 1 if self.fast_dev_run else self.max_epochs
-        for epoch in range(epochs):
+        for epoch in range(first_epoch, epochs):
             self.current_epoch = module.current_epoch = epoch
             if self.freeze_epochs > 0 and epoch >= self.freeze_epochs and not self._unfrozen and \
                     hasattr(module.model, "set_preprocessor_trainable"):
-                module.model.set_preprocessor_trainable(True)  # callbacks.py:31-46
+                module.model.set_preprocessor_trainable(True)
                 self._unfrozen = True
                 if self.verbose:
-                    print(f"[trainer] epoch {epoch}: unfreezing the input preprocessor")
+                    print(f"[trainer] epoch {epoch}: input preprocessor unfrozen")
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
             module.train()
             t0 = time.time()
-            n = 0
             for i, batch in enumerate(train_loader):
                 self.training_step(module, _to_device(batch, self.device), i)
-                n += 1
                 if self.fast_dev_run:
                     break
             logs = self._flush_epoch_logs()
             if val_loader is not None:
                 logs.update(self.validate(module, val_loader, "val"))
-            if self.sched_cfg and self.sched_cfg.get("interval", "epoch") != "step":
-                sch = self.sched_cfg["scheduler"]
-                if self.sched_cfg.get("reduce_on_plateau"):
-                    if monitor in logs:  # strict=False: skip silently when the metric is missing
-                        sch.step(logs[monitor])
-                else:
-                    sch.step()
+            self._step_epoch_scheduler(logs)
             logs["lr"] = self.optimizer.param_groups[0]["lr"]
             logs["epoch_time_s"] = time.time() - t0
             self.history.append(logs)
             self.logged.update(logs)
             if self.verbose:
                 print(f"[epoch {epoch}] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(logs.items())))
-            if monitor in logs:  # EarlyStopping(monitor, patience, mode)
-                v = logs[monitor]
-                if best is None or (v > best if mode_max else v < best):
-                    best, bad = v, 0
-                else:
-                    bad += 1
-                    if bad >= self.patience:
-                        break
+            if self.checkpointer is not None and val_loader is not None:
+                self.checkpointer.after_validation(self, module, logs)
+            if self._early_stop(logs):
+                self.should_stop = True
+                break
         return self.history
 
-    def test(self, module, loader):
-        module.trainer = self
-        module.to(self.device)
-        return self.validate(module, loader, "test")
+    def _step_epoch_scheduler(self, logs):
+        if not self.sched_cfg or self.sched_cfg.get("interval", "epoch") == "step":
+            return
+        sch = self.sched_cfg["scheduler"]
+        if self.sched_cfg.get("reduce_on_plateau"):
+            if self.monitor in logs:  # strict=False: a missing metric skips the scheduler silently
+                sch.step(logs[self.monitor])
+        else:
+            sch.step()
+
+    def _early_stop(self, logs) -> bool:
+        """EarlyStopping(monitor, patience, mode, strict=False): stop after `patience` validations without improvement."""
+        if self.monitor not in logs:
+            return False
+        v = logs[self.monitor]
+        improved = self._es_best is None or (v > self._es_best if self.monitor_mode == "max" else v < self._es_best)
+        if improved:
+            self._es_best, self._es_bad = float(v), 0
+            return False
+        self._es_bad += 1
+        return self._es_bad >= self.patience
+
+
+def _plain(obj):
+    """Containers of tensors / numbers / strings only, so the file loads under torch.load(weights_only=True)."""
+    if isinstance(obj, dict):
+        return {str(k) if not isinstance(k, (int, str)) else k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    if torch.is_tensor(obj) or isinstance(obj, (int, float, str, bool)) or obj is None:
+        return obj
+    return str(obj)

@@ -1,41 +1,36 @@
-"""Config plumbing of the path: `load_config` with the reference's semantics (src/utils.py:311-359): YAML + expansion
-of ${ENV} / ~ in every string + transparent flattening of W&B-exported configs."""
+"""Config file loading for the path (the reference's `load_config`, src/utils.py:311-359, minus its W&B-export unwrapping:
+W&B is outside the hot path): YAML -> plain dict with `$VAR` / `${VAR}` / `~` expanded in every
+string value, however deeply nested."""
 from __future__ import annotations
 
 import os
+from typing import Any
 
 import yaml
 
-__all__ = ["load_config"]
+__all__ = ["load_config", "expand_strings"]
 
 
-def _expand(item):
-    if isinstance(item, str):
-        return os.path.expanduser(os.path.expandvars(item))
-    if isinstance(item, dict):
-        return {k: _expand(v) for k, v in item.items()}
-    if isinstance(item, list):
-        return [_expand(v) for v in item]
-    return item
+def expand_strings(node: Any) -> Any:
+    """A copy of a YAML tree (dicts / lists / scalars) with environment variables and the home directory expanded in
+    its strings.  Keys are left alone; non-string scalars pass through."""
+    if isinstance(node, str):
+        return os.path.expanduser(os.path.expandvars(node))
+    if isinstance(node, dict):
+        return {key: expand_strings(value) for key, value in node.items()}
+    if isinstance(node, (list, tuple)):
+        return [expand_strings(value) for value in node]
+    return node
 
 
-def _maybe_flatten_wandb_cfg(cfg):
-    if not isinstance(cfg, dict):
-        return cfg
-    inner = cfg.get("config")
-    if isinstance(inner, dict) and isinstance(inner.get("value"), dict):
-        return inner["value"]
-    flattened, saw = {}, False
-    for k, v in cfg.items():
-        if isinstance(v, dict) and "value" in v and isinstance(v["value"], (dict, list, str, int, float, bool, type(None))):
-            flattened[k] = v["value"]
-            saw = True
-        elif k != "_wandb":
-            flattened[k] = v
-    return flattened if saw else cfg
-
-
-def load_config(config_path):
-    with open(config_path, "r") as f:
-        raw = yaml.safe_load(f)
-    return _expand(_maybe_flatten_wandb_cfg(raw))
+def load_config(config_path: str) -> dict:
+    with open(config_path, "r") as fh:
+        tree = yaml.safe_load(fh)
+    if tree is None:
+        return {}
+    if not isinstance(tree, dict):
+        raise ValueError(f"{config_path}: expected a mapping at the top level, got {type(tree).__name__}")
+    if "_wandb" in tree or isinstance((tree.get("config") or {}).get("value") if isinstance(tree.get("config"), dict) else None, dict):
+        raise ValueError(f"{config_path} looks like a W&B-exported config ('_wandb' / 'config.value' wrappers); "
+                         f"W&B is outside this path -- pass the plain experiment YAML")
+    return expand_strings(tree)
