@@ -154,18 +154,26 @@ def test_freeze_schedule_unfreezes_preprocessor(dev, tmp_path):
     step0 = module.training_step
 
     def spy(batch, idx):
-        seen.append((trainer.current_epoch, all(p.requires_grad for p in pre.parameters()),
-                     [p.detach().clone() for p in pre.parameters()]))
+        seen.append((trainer.current_epoch, pre._is_frozen, len(list(pre.parameters())), pre.linear.weight.detach().clone()))
         return step0(batch, idx)
 
     module.training_step = spy
     trainer.fit(module, Batches(32, 1), Batches(16, 2))
     e0 = [s for s in seen if s[0] == 0]
     e1 = [s for s in seen if s[0] == 1]
-    assert e0 and e1 and not any(s[1] for s in e0) and all(s[1] for s in e1)
-    assert all(torch.equal(a, b) for a, b in zip(e0[0][2], e1[0][2]))          # frozen through epoch 0
-    after = [p.detach().clone() for p in pre.parameters()]
-    assert any(not torch.equal(a, b) for a, b in zip(e1[0][2], after))          # trained in epoch 1
+    assert len(e0) == 2 and len(e1) == 2
+    assert all(s[1] and s[2] == 0 for s in e0)            # epoch 0: frozen = buffers, nothing for autograd
+    assert all((not s[1]) and s[2] == 2 for s in e1)      # epoch 1 on: weight + bias are Parameters
+    assert torch.equal(e0[0][3], e1[0][3])                # untouched while frozen
+    w = pre.linear.weight
+    assert isinstance(w, torch.nn.Parameter) and w.requires_grad and w.grad is not None and float(w.grad.abs().sum()) > 0
+    assert trainer._unfrozen
+    # permanent freeze never unfreezes
+    cfg["warmup"]["freeze_epochs"] = -1
+    cfg["model"]["image_size"] = 4096
+    module2, trainer2 = make(cfg)
+    trainer2.fit(module2, Batches(16, 1), Batches(16, 2))
+    assert module2.model.name.startswith("PCA64_fzperm") and module2.model.preprocessor._is_frozen and not trainer2._unfrozen
 
 
 def test_save_resume_and_eval_only(dev, tmp_path, monkeypatch):

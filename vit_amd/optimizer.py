@@ -67,6 +67,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 m.copy_(self._m)
                 v.copy_(self._v)
             self._m, self._v = m, v
+        if self._sq is None or self._sq.device != eng.flat.device:
             self._sq = torch.zeros(1, dtype=torch.float32, device=eng.flat.device)
 
     def _active_ranges(self):
