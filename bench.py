@@ -90,6 +90,8 @@ def main():
                     help="bf16-mixed = the BASELINE.json metric; 32 = the fp32-class mode (x3 GEMMs), for the record only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N = 1: launch the step's kernels eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
     ap.add_argument("--launch-check", action="store_true",
                     help="rank plumbing only (no GPU): every rank joins a gloo group, rank 0 prints {world, sum of ranks}")
@@ -135,6 +137,8 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
         module = ViTLModule(config=config)
+    use_graph = world == 1 and not args.no_graph
+    config["train"]["hip_graph"] = use_graph
     trainer = Trainer(config["train"], device=dev, verbose=False)
     trainer._setup(module)
     module.train()
@@ -190,6 +194,7 @@ def main():
     if not args.no_kernel_timing:
         n_inst = min(args.steps, 20)
         timing_on[0] = True
+        trainer.use_graph = False  # the per-GEMM event brackets need the eager launches
         barrier()
         t1 = time.perf_counter()
         for i in range(n_inst):
@@ -303,7 +308,8 @@ def main():
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
                        "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
-                       "final_loss": final_loss},
+                       "final_loss": final_loss,
+                       "launch": "one hipGraph replay per step" if use_graph else "eager launches"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "comm": comm, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)

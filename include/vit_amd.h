@@ -13,7 +13,9 @@
  *   - alignment: every base pointer 16-byte aligned, every leading/inner dimension of a bf16 GEMM operand a multiple
  *     of 8 elements (of an f32 one: 4), checked on the host before any launch (VIT_ERR_ARG otherwise);
  *   - dropout masks are a pure function of (seed, site, row, col): forward and backward regenerate them, nothing is
- *     stored.
+ *     stored;
+ *   - state: the handle (workspace pointer, optional per-step state pointer) and the process-wide kernel-selection
+ *     knobs of vit_set_option; nothing else persists between calls.
  */
 #ifndef VIT_AMD_H_
 #define VIT_AMD_H_
@@ -66,6 +68,21 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                results are meaningless while it is non-zero.
  *                Returns VIT_ERR_ARG for an unknown name. */
 int vit_set_option(const char* name, int value);
+
+/* Per-step state in device memory, for a training step captured as a hipGraph (HIP streams and graphs instead of a tracing
+ * compiler: kernel arguments are frozen at capture, so what changes from step to step must be read from memory).
+ * `state`: 32 bytes, 16-byte aligned: { u32 key0, key1; f32 lr, bc1, rsqrt_bc2; u32 step; u32 pad[2] }, caller-owned.
+ * While bound (NULL unbinds), every call through this handle that takes (dropout_p, seed, site) XORs the state's keys
+ * into its dropout keys at kernel entry: the masks of a replay are those of (seed, site, step).  vit_step_advance (one
+ * tiny kernel, first node of the captured step) does step += 1, derives the keys from (base_seed, step) and AdamW's
+ * bias corrections from step; `lr` is the host's to write (a scheduler changes it between replays).
+ * vit_adamw_step_dyn = vit_adamw_step with lr / bias corrections read from the state.
+ * Replaces what Lightning's loop hands torch per step: the generator advance behind nn.Dropout and optimizer.step()'s
+ * step count (basemodule.py:230-251). */
+int vit_step_state_bind(vit_handle h, void* state);
+int vit_step_advance(vit_handle h, uint64_t base_seed, float beta1, float beta2, vit_stream stream);
+int vit_adamw_step_dyn(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1,
+                       float beta2, float eps, float weight_decay, const float* sqnorm, float max_norm, vit_stream stream);
 
 /* ------------------------------------------------------------------------------------------------ GEMM
  * C = epilogue(alpha * op(A) * op(B)), bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.

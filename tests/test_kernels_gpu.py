@@ -717,3 +717,43 @@ def test_attention_delta_residual(dev, B, H, T, dh):
     print(f"[T={T}] dq/dk/dv rel err without residual {e0[0]:.2e}/{e0[1]:.2e}/{e0[2]:.2e}, with {e1[0]:.2e}/{e1[1]:.2e}/{e1[2]:.2e}")
     assert e1[0] < 0.5 * e0[0] and e1[1] < 0.5 * e0[1], (e0, e1)
     assert max(e1) < 1.5e-2, e1
+
+
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 197, 64), (1, 2, 224, 64), (1, 2, 240, 32), (3, 1, 17, 64), (1, 2, 64, 64)])
+@pytest.mark.parametrize("drop", [(0.0, 0, 0), (0.1, 7, 5)])
+def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
+    """The single-kernel backward (one workgroup per head; dS through the LDS) against the dQ + dK/dV pair: same dropout
+    masks, same delta, so the results agree to bf16 rounding of differently ordered sums; column sums likewise; and both
+    against fp64 autograd."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    scale = dh ** -0.5
+    qkv = bf(randn((B * T, 3 * H * dh), dev, 70))
+    lo = torch.empty((B * T, H * dh), dtype=torch.bfloat16, device=dev)
+    ctx, lse = vf.attention_fwd(qkv, B, H, T, dh, scale, dropout=drop, ctx_lo=lo)
+    dctx = bf(randn((B * T, H * dh), dev, 71))
+    out = {}
+    try:
+        for fused in (0, 1, 2):  # two-kernel path, fused with 8 waves, fused with 16 waves
+            _cabi.set_option("attn_bwd_fused", fused)
+            cs = torch.zeros(3 * H * dh, device=dev)
+            delta = torch.zeros((B * H, T), device=dev)
+            d = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale, dropout=drop, colsum_out=cs, ctx_lo=lo, delta=delta)
+            out[fused] = (d.clone(), cs.clone(), delta.clone())
+    finally:
+        _cabi.set_option("attn_bwd_fused", 1)
+    a, b_ = out[0], out[1]
+    assert rel(out[2][0], a[0]) < 6e-3 and rel(out[2][2], a[2]) < 1e-5
+    assert rel(out[2][1], out[2][0].float().sum(0)) < 1e-5
+    assert rel(b_[0], a[0]) < 6e-3, rel(b_[0], a[0])
+    assert rel(b_[2], a[2]) < 1e-5
+    assert rel(b_[1], b_[0].float().sum(0)) < 1e-5  # column sums of what was stored
+    if drop[0] == 0.0:
+        q64 = qkv.double().requires_grad_(True)
+        ref, _, _ = attn_ref(q64, B, H, T, dh, scale)
+        ref.backward(dctx.double())
+        g = q64.grad.view(B * T, 3, H * dh)
+        dd = b_[0].double().view(B * T, 3, H * dh)
+        for i in range(3):
+            assert rel(dd[:, i], g[:, i]) < 1.2e-2, (i, rel(dd[:, i], g[:, i]))

@@ -334,3 +334,46 @@ def test_fp16_precision_is_refused(dev):
     module, _ = make(c1_config())
     with pytest.raises(ValueError, match="fp16"):
         module.model.set_precision("16-mixed")
+
+
+@pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
+def test_hip_graph_step_equals_eager(dev, precision):
+    """train.hip_graph: the captured step (vit_amd/graph.py) must be the eager step.  With dropout switched off in the
+    config both paths are deterministic functions of (weights, batch): 4 graph replays == 4 eager steps bit for bit, incl.
+    AdamW's bias corrections (step count read from the device record) and a mid-run learning-rate change; the capture's
+    warm-up steps leave no trace.  With dropout on, every replay draws new masks."""
+    from vit_amd.graph import GraphedTrainStep
+
+    batches = list(Batches(64, 5))
+    finals = {}
+    for mode in ("eager", "graph"):
+        cfg = c1_config(precision=precision, hip_graph=(mode == "graph"))
+        module, trainer = make(cfg)
+        module.model.config.hidden_dropout_prob = 0.0
+        module.model.config.attention_probs_dropout_prob = 0.0
+        trainer._setup(module)
+        module.train()
+        losses = []
+        for i in range(4):
+            if i == 2:
+                trainer.optimizer.param_groups[0]["lr"] = 3e-4
+            b = tuple(t.cuda() for t in batches[i % 2])
+            losses.append(float(trainer.training_step(module, b, i)))
+        finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()},
+                        trainer.optimizer._step, float(trainer.optimizer.last_grad_norm))
+        if mode == "graph":
+            assert isinstance(trainer._graphed, GraphedTrainStep)
+    assert finals["eager"][0] == finals["graph"][0], (finals["eager"][0], finals["graph"][0])
+    assert finals["eager"][2] == finals["graph"][2] == 4
+    assert finals["eager"][3] == finals["graph"][3]
+    for k in finals["eager"][1]:
+        assert torch.equal(finals["eager"][1][k], finals["graph"][1][k]), k
+    # dropout on: same inputs, same weights (lr = 0) -> different masks on every replay, hence different losses
+    cfg = c1_config(precision=precision, hip_graph=True)
+    cfg["opt"]["lr"] = 0.0
+    module, trainer = make(cfg)
+    trainer._setup(module)
+    module.train()
+    b = tuple(t.cuda() for t in batches[0])
+    seen = {round(float(trainer.training_step(module, b, i)), 7) for i in range(4)}
+    assert len(seen) == 4, seen

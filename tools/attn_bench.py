@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Resident attention kernels at the ViT-B shape (B=256, H=12, T=197, dh=64), per attn_split setting."""
+"""Attention kernels at the ViT-B shape (B=256, H=12, T=197, dh=64): forward, two-kernel backward, fused backward;
+with / without dropout and the context residual.  Prints us per call and the effective HBM rate against the algorithmic
+bytes (fwd: qkv + ctx (+lo); bwd: qkv + ctx (+lo) + dctx + dqkv)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,28 +13,32 @@ M, D = B * T, H * dh
 qkv = (torch.randn(M, 3 * D, device=dev) * 0.5).to(torch.bfloat16)
 dctx = (torch.randn(M, D, device=dev) * 0.5).to(torch.bfloat16)
 ctx = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+lo = torch.empty_like(ctx)
 lse = torch.empty(B * H, T, device=dev)
 dqkv = torch.empty_like(qkv); delta = torch.empty(B * H, T, device=dev)
-drop = (0.1, 1, 2)
-def t(fn, n=5):
-    fn(); torch.cuda.synchronize()
+cs = torch.empty(3 * D, device=dev)
+def t(fn, n=10):
+    fn(); fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+sc = dh ** -0.5
 for dp in ((0.1, 1, 2), (0.0, 0, 0)):
-    _cabi.set_option("attn_split", 2)
-    f = t(lambda: vf.attention_fwd(qkv, B, H, T, dh, dh ** -0.5, dropout=dp, ctx=ctx, lse=lse))
-    b = t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=dp, dqkv=dqkv, delta=delta))
-    print(f"dropout p={dp[0]}: fwd {f:6.1f} us  bwd {b:6.1f} us", flush=True)
-ref = None
-for rnd in range(1):
-    for split in (1, 2):
-        _cabi.set_option("attn_split", split)
-        f = t(lambda: vf.attention_fwd(qkv, B, H, T, dh, dh ** -0.5, dropout=drop, ctx=ctx, lse=lse))
-        b = t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, dh ** -0.5, dropout=drop, dqkv=dqkv, delta=delta))
-        if ref is None: ref = (ctx.clone(), dqkv.clone())
-        assert torch.equal(ctx, ref[0]) and torch.equal(dqkv, ref[1]), split
-        print(f"attn_split={split}: fwd {f:6.1f} us  bwd {b:6.1f} us", flush=True)
-_cabi.set_option("attn_split", 2)
+    for use_lo in (True, False):
+        l = lo if use_lo else None
+        f = t(lambda: vf.attention_fwd(qkv, B, H, T, dh, sc, dropout=dp, ctx=ctx, lse=lse, ctx_lo=l))
+        fb = (M * 3 * D + M * D * (2 if use_lo else 1)) * 2
+        bb = (M * 3 * D * 2 + M * D * (3 if use_lo else 2)) * 2
+        res = {}
+        for fused in (0, 1, 2):
+            _cabi.set_option("attn_bwd_fused", fused)
+            res[fused] = t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, sc, dropout=dp, dqkv=dqkv, delta=delta,
+                                                    colsum_out=cs, ctx_lo=l))
+            res[fused, "d"] = dqkv.clone()
+        err = float((res[0, "d"].float() - res[1, "d"].float()).norm() / res[0, "d"].float().norm())
+        err2 = float((res[0, "d"].float() - res[2, "d"].float()).norm() / res[0, "d"].float().norm())
+        print(f"dropout {dp[0]} residual {int(use_lo)}: fwd {f:6.1f} us ({fb / f / 1e6:.2f} TB/s)  bwd two-kernel {res[0]:6.1f} us  "
+              f"fused8 {res[1]:6.1f} us  fused16 {res[2]:6.1f} us ({bb / res[2] / 1e6:.2f} TB/s)  rel diffs {err:.1e} {err2:.1e}", flush=True)
+_cabi.set_option("attn_bwd_fused", 1)

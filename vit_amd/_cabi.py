@@ -54,6 +54,9 @@ _PROTOS = {
     "vit_destroy": [_P],
     "vit_set_workspace": [_P, _P, _SZ],
     "vit_set_option": [C.c_char_p, _I],
+    "vit_step_state_bind": [_P, _P],
+    "vit_step_advance": [_P, _U64, _F, _F, _P],
+    "vit_adamw_step_dyn": [_P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _P],
     "vit_gemm": [_P, C.POINTER(GemmDesc), _P],
     "vit_last_gemm_kernel": [],
     "vit_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _F, _U64, _U64, _P, _P],

@@ -9,12 +9,13 @@ struct vit_ctx {
   int device;
   void* ws;
   size_t ws_bytes;
+  const void* step_state;  // device memory: vit::StepState, or NULL (vit_step_state_bind)
 };
 
 namespace vit {
 
-extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail;  // gemm2.hip
-extern int g_attn_split, g_attn_res_max_t;         // attention.hip
+extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
+extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_debug;  // attention.hip
 
 static thread_local char g_err[512] = "";
 thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
@@ -25,6 +26,8 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+const StepState* ctx_step_state(vit_handle h) { return h ? (const StepState*)h->step_state : nullptr; }
 
 void* ctx_workspace(vit_handle h, size_t* bytes) {
   if (!h) {
@@ -56,6 +59,7 @@ int vit_create(vit_handle* out, int device) {
   c->device = device;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->step_state = nullptr;
   *out = c;
   return VIT_OK;
 }
@@ -79,12 +83,24 @@ int vit_set_option(const char* name, int value) {
     vit::g_attn_split = value;
     return VIT_OK;
   }
+  if (strcmp(name, "attn_debug") == 0) {
+    vit::g_attn_debug = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "attn_bwd_fused") == 0) {
+    vit::g_attn_bwd_fused = value;
+    return VIT_OK;
+  }
   if (strcmp(name, "attn_res_max_t") == 0) {
     vit::g_attn_res_max_t = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_half_tail") == 0) {
     vit::g_half_tail = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "gemm_ngroups") == 0) {
+    vit::g_grp2 = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_balance_wgs") == 0) {
@@ -102,6 +118,13 @@ int vit_set_option(const char* name, int value) {
   }
   vit::set_error("vit_set_option: unknown option '%s'", name);
   return VIT_ERR_ARG;
+}
+
+int vit_step_state_bind(vit_handle h, void* state) {
+  VIT_CHECK(h, VIT_ERR_ARG, "vit_step_state_bind: null handle");
+  VIT_CHECK(((uintptr_t)state & 15) == 0, VIT_ERR_ARG, "vit_step_state_bind: state must be 16-byte aligned");
+  h->step_state = state;
+  return VIT_OK;
 }
 
 int vit_set_workspace(vit_handle h, void* ws, size_t bytes) {

@@ -39,6 +39,7 @@ struct AttnArgs {
   float scale;
   DropCfg drop;
   int nsplit, wpw;  // resident kernels: workgroups per (batch, head) and waves per workgroup (row tiles are dealt in order)
+  int dbg;           // timing diagnostics for the fused backward (vit_set_option("attn_debug")): skip pieces; results invalid
   float* csum_part;  // resident backward kernels: [B * nsplit * wpw][3 * H * dh] per-wave column sums of dqkv as stored, or NULL
 };
 
@@ -110,6 +111,7 @@ __device__ __forceinline__ void store_lo(short* dst, const f32x4& v, const u32x2
 // ------------------------------------------------------------------------------------------------ forward
 template <int DH>
 __global__ __launch_bounds__(AW * 64) void attn_fwd_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2];
   char* Kimg = smem;
   char* Vimg = smem + RT * DH * 2;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(AW * 64) void attn_fwd_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------------ dQ
 template <int DH>
 __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2];
   char* Kimg = smem;
   char* Vimg = smem + RT * DH * 2;
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int DH>
 __global__ __launch_bounds__(AW * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   __shared__ __attribute__((aligned(16))) char smem[2 * RT * DH * 2 + 2 * RT * 4];
   char* Qimg = smem;
   char* Oimg = smem + RT * DH * 2;
@@ -512,10 +516,14 @@ __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, lon
 
 template <int DH, int RQ>
 __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
+  // workgroups go to the XCDs round-robin (blockIdx % 8): deal each XCD a contiguous run of logical ids, so the nsplit
+  // workgroups that stage the SAME head's K / V sit on one XCD, back to back, and the second one finds them in that L2
+  const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int bh = wg / p.nsplit, part = wg - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
   const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
@@ -649,6 +657,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
 
 template <int DH, int RQ>
 __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -795,6 +804,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
 
 template <int DH, int RQ>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
@@ -951,6 +961,309 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   }
 }
 
+// ======================================================================================= fused backward (T <= 240)
+// ONE kernel per attention backward when a head's Q, dO and K fit the LDS together with one half of the dS matrix: one
+// workgroup of 8 waves per (batch, head); every tensor of the head is read from HBM exactly once and S / P / dP are
+// recomputed once (5 products instead of the two-kernel path's 7: the resident dQ + dK/dV pair above moved 1.36 GB per
+// ViT-B layer and ran at HBM speed).  No atomics (the reference trains with deterministic=True, basemodule.py:250):
+//   phase A (owner = key, as in the dK/dV kernel): wave w keeps K, V of keys [32w, 32w+32) in registers and walks the
+//     query pairs (32 rows) of the current half: S = Q K^T, dP = dO V^T, P, dS; dV += P~^T dO, dK += dS^T Q stay in
+//     registers; dS (bf16) goes to the LDS as [key][query] -- 4 consecutive queries of one key per lane, one 8-byte store;
+//   phase B (owner = query): wave w takes query tile w of the half and sums dQ = dS K over ALL keys, both operands by
+//     transposing reads (K image [key][d], dS image [key][query]); dQ leaves in bf16, its column sums join the others.
+// Two halves of 128 queries keep the dS image at 60 KiB: LDS = 3 x 26 KiB (Q, dO, K) + 58.5 KiB + statistics = 138 KiB at
+// T = 197, one workgroup per CU.  delta = rowsum(dO o (O + O_lo)) is computed up front from global O (loads issued before
+// the staging barrier) and dO from the LDS.
+constexpr int DSP = 288;  // bytes per key row of the dS image: 128 queries x 2 B + 32 (4 consecutive rows hit disjoint banks)
+
+template <int DH>
+__device__ __forceinline__ void load_all_tiles3(char* imgA, const short* ga, long lda, char* imgB, const short* gb, long ldb,
+                                                char* imgC, const short* gc, long ldc_, int T, int dh, int rows_alloc, int tid,
+                                                int nthr) {
+  constexpr int CPR = DH / 8, MAXI = 4;
+  const int total = rows_alloc * CPR;
+  for (int base = 0; base < total; base += MAXI * nthr) {
+    i32x4 va[MAXI], vb[MAXI], vc[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int q = base + tid + i * nthr;
+      const int r = q / CPR, c = q % CPR;
+      va[i] = vb[i] = vc[i] = (i32x4){0, 0, 0, 0};
+      if (q < total && r < T && c * 8 < dh) {
+        va[i] = *(const i32x4*)(ga + (long)r * lda + c * 8);
+        vb[i] = *(const i32x4*)(gb + (long)r * ldb + c * 8);
+        vc[i] = *(const i32x4*)(gc + (long)r * ldc_ + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+      const int q = base + tid + i * nthr;
+      if (q < total) {
+        const int r = q / CPR, c = q % CPR;
+        const int off = (r >> 6) * (RT * DH * 2) + tile_off<DH>(r & 63, c);
+        *(i32x4*)(imgA + off) = va[i];
+        *(i32x4*)(imgB + off) = vb[i];
+        *(i32x4*)(imgC + off) = vc[i];
+      }
+    }
+  }
+}
+
+// NW waves per workgroup: 8 (each wave owns 32 keys, two 16-key tiles) or 16 (16 keys each: half the registers per wave,
+// so 4 waves per SIMD instead of 2 hide the LDS / MFMA / exp latencies the 2-wave form showed as 42 % parked wave-cycles)
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TILE = RT * DH * 2, RQ = 16 / NW, CPR = DH / 8, RPI = NW * 64 / CPR /* rows per delta iteration */;
+  constexpr int DIT = (240 + RPI - 1) / RPI, ND = DH / 16, WPQ = NW / 8 /* waves per query tile in phase B */, DPW = ND / WPQ;
+  static_assert(DPW >= 1, "phase B: at least one d-tile per wave");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  // workgroups of one XCD (blockIdx % 8) take consecutive heads: neighbours in time share that XCD's L2 for the weights of
+  // nothing -- but the (batch, head) order keeps a sample's rows of qkv / dctx together in one L2
+  const int nwg = gridDim.x;
+  const int bh = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh;
+  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
+  const short* ob = p.ctx + (long)b * T * ldc + h * dh;
+  const int R = (T + 15) & ~15;
+  char* Qimg = smem;
+  char* Oimg = smem + R * (DH * 2);
+  char* Kimg = smem + 2 * R * (DH * 2);
+  char* dSimg = smem + 3 * R * (DH * 2);
+  float* lse_s = (float*)(dSimg + R * DSP);
+  float* del_s = lse_s + R;
+
+  // ---- loads in flight before the first barrier: this wave's K / V rows, the O (+ residual) chunks of the delta pre-pass
+  const int k00 = wave * RQ * 16;
+  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, dh, l15, lg);
+    load_own<DH>(vf[rq], vb, ld, k00 + rq * 16, T, dh, l15, lg);
+  }
+  i32x4 og[DIT], ol[DIT];
+  const int drow0 = wave * (64 / CPR) + lane / CPR, dch = lane % CPR;
+#pragma unroll
+  for (int it = 0; it < DIT; ++it) {
+    const int row = drow0 + it * RPI;
+    og[it] = ol[it] = (i32x4){0, 0, 0, 0};
+    if (row < T && dch * 8 < dh) {
+      og[it] = *(const i32x4*)(ob + (long)row * ldc + dch * 8);
+      if (p.ctx_lo) ol[it] = *(const i32x4*)(p.ctx_lo + (ob - p.ctx) + (long)row * ldc + dch * 8);
+    }
+  }
+  if (!(p.dbg & 4)) load_all_tiles3<DH>(Qimg, qb, ld, Oimg, dob, ldc, Kimg, kb_, ld, T, dh, R, tid, NW * 64);
+  __syncthreads();
+  // ---- delta[q] = sum_d dO[q,d] (O[q,d] + O_lo[q,d]), lse in the exp2 domain
+#pragma unroll
+  for (int it = 0; it < DIT; ++it) {
+    const int row = drow0 + it * RPI;
+    if (row < R) {  // whole CPR-lane groups share `row`: the shuffles below stay inside the group
+      const bf16x8 dv = *(const bf16x8*)(Oimg + (row >> 6) * TILE + tile_off<DH>(row & 63, dch));
+      const bf16x8 o8 = __builtin_bit_cast(bf16x8, og[it]), l8 = __builtin_bit_cast(bf16x8, ol[it]);
+      float d_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(dv[e]);
+#pragma unroll
+      for (int m = 1; m < CPR; m <<= 1) d_ += __shfl_xor(d_, m, 64);
+      if (dch == 0) {
+        del_s[row] = row < T ? d_ : 0.f;
+        lse_s[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
+        if (row < T) p.delta[(long)bh * T + row] = d_;
+      }
+    }
+  }
+  __syncthreads();
+
+  const float c = p.scale * LOG2E;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+  const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
+  const int nq = R >> 4, npairs = (nq + 1) >> 1, nks = (T + 31) >> 5;
+  f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16], csq[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) csq[i] = zero4();
+#pragma unroll
+  for (int i = 0; i < DH / 16; ++i) {
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
+  }
+
+  for (int half = 0; half < 2; ++half) {
+    const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
+    if (pp0 >= npairs) break;  // uniform over the workgroup
+    // ------------------------------------------------------------------ phase A: this wave's keys x the half's queries
+    if (k00 < R && !(p.dbg & 2)) {
+      for (int pp = pp0; pp < pp1; ++pp) {
+        const int qb0 = pp * 32;
+        const char* Qt = Qimg + (qb0 >> 6) * TILE;
+        const char* Ot = Oimg + (qb0 >> 6) * TILE;
+        const int u32 = qb0 & 32;  // row offset of the pair inside its 64-row tile
+        u32x2 pdh[RQ][2], dsh[RQ][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int q0 = qb0 + jj * 16;
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
+          if (q0 < R) {
+            f32x4 s_[RQ], dp[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
+#pragma unroll
+            for (int s = 0; s < DH / 32; ++s) {
+              const bf16x8 qfr = frag_rows<DH>(Qt, u32 + jj * 16, s, l15, lg);
+              const bf16x8 ofr = frag_rows<DH>(Ot, u32 + jj * 16, s, l15, lg);
+#pragma unroll
+              for (int rq = 0; rq < RQ; ++rq) {
+                s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
+                dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
+              }
+            }
+            const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
+            const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              const unsigned key = k00 + rq * 16 + l15;
+              float pdv[4], dsv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
+                float mk = 1.f;
+                if (p.drop.thr) {
+                  const unsigned idx32 = (unsigned)(q0 + lg * 4 + r) * half_cols + (key >> 1);
+                  const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
+                  const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+                  mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
+                }
+                pdv[r] = pr * mk;
+                dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+              }
+              pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
+              dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+              if (k00 + rq * 16 < R)  // [key][query of the half]: 4 consecutive queries of this lane's key
+                *(u32x2*)(dSimg + (k00 + rq * 16 + l15) * DSP + (q0 - pp0 * 32 + lg * 4) * 2) = dsh[rq][jj];
+            }
+          }
+        }
+        bf16x8 pf[RQ], df[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
+          df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
+        }
+        const int rb1 = (qb0 + 16 < R) ? u32 + 16 : u32;  // an un-staged block: its P and dS are 0
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          const bf16x8 otf = frag_cols<DH>(Ot, u32, rb1, dt * 16, l15, lg);
+          const bf16x8 qtf = frag_cols<DH>(Qt, u32, rb1, dt * 16, l15, lg);
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) {
+            dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
+            dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase B: dQ of query tile (2 pp0 + wave) over all keys
+    const int qt = pp0 * 2 + wave / WPQ, dt0 = (wave % WPQ) * DPW;
+    if (qt < nq && qt < pp1 * 2 && !(p.dbg & 1)) {
+      f32x4 dqt[DPW];
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) dqt[i] = zero4();
+      const int tq = l15 >> 2, tp = l15 & 3;
+      const char* dcol = dSimg + ((wave / WPQ) * 16 + 4 * tp) * 2;
+      for (int ks = 0; ks < nks; ++ks) {
+        const int kb = ks * 32;
+        const bool hi_ok = kb + 16 < R;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 4 * lg + tq) * DSP));
+        bf16x4 hi = {0, 0, 0, 0};
+        if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16 + 4 * lg + tq) * DSP));
+        const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const char* Kt = Kimg + (kb >> 6) * TILE;
+        const int r0 = kb & 63;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+          const bf16x8 ktf = frag_cols<DH>(Kt, r0, hi_ok ? r0 + 16 : r0, (dt0 + i) * 16, l15, lg);
+          dqt[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[i], 0, 0, 0);
+        }
+      }
+      const int q = qt * 16 + l15;
+      if (q < T) {
+        short* o = p.dqkv + ((long)b * T + q) * ld + h * dh;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+          const int d = (dt0 + i) * 16 + lg * 4;
+          if (d < dh) {
+            const f32x4 v = dqt[i] * p.scale;
+            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            *(u32x2*)(o + d) = pk;
+            csq[i] += bf_round4(pk);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int dt0_ = (wave % WPQ) * DPW;
+  // ---- dK, dV of this wave's keys; per-wave column sums of everything this wave stored (the QKV bias gradient)
+  f32x4 csk[DH / 16], csv[DH / 16];
+#pragma unroll
+  for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    const int key = k00 + rq * 16 + l15;
+    if (key < T && !(p.dbg & 8)) {
+      short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * dh + h * dh;
+      short* ov = ok + p.H * dh;
+#pragma unroll
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        const int d = dt * 16 + lg * 4;
+        if (d < dh) {
+          const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
+          u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+          u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          *(u32x2*)(ok + d) = pk;
+          *(u32x2*)(ov + d) = pv;
+          csk[dt] += bf_round4(pk);
+          csv[dt] += bf_round4(pv);
+        }
+      }
+    }
+  }
+  if (p.csum_part) {
+    float* csum = p.csum_part + ((long)b * NW + wave) * ld + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DH / 16; ++dt) {
+      const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
+      f32x4 tq_ = zero4();  // this wave summed dQ only over its own d-tiles [dt0, dt0 + DPW)
+#pragma unroll
+      for (int i = 0; i < DPW; ++i)
+        if (dt == dt0_ + i) tq_ = rows16_sum(csq[i]);
+      const int d = dt * 16 + lg * 4;
+      if (l15 == 0 && d < dh) {
+        *(f32x4*)(csum + d) = tq_;
+        *(f32x4*)(csum + p.H * dh + d) = tk;
+        *(f32x4*)(csum + 2 * p.H * dh + d) = tv;
+      }
+    }
+  }
+}
+
+int g_attn_debug = 0;
+int g_attn_bwd_fused = 1;  // vit_set_option("attn_bwd_fused"): 0 = always the two-kernel backward
+
+static bool fused_fits(int T, int dh) {
+  const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
+  return T <= 240 && rows * (3 * dhp * 2 + DSP + 8) <= 160 * 1024;
+}
+
 // resident kernels: a (batch, head)'s whole K/V (or Q/dO) in the LDS -- at head_dim 64 up to T = 592 rows (2 x 74 KiB; the
 // backward adds 4.6 KiB of row statistics): ViT-L/16 384^2 (T = 577) fits, one workgroup per CU, three workgroups of 7
 // waves per head
@@ -1026,6 +1339,7 @@ __device__ __forceinline__ float dot_row(const float* __restrict__ a_lds, const 
 // MODE 0: forward (ctx, lse, optional probs)   MODE 1: dQ (+ delta)
 template <int MODE>
 __global__ __launch_bounds__(256) void attn32_row_kernel(Attn32Args p) {
+  resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) float sm32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wib;  // (b*H + h)*T + q
@@ -1104,6 +1418,7 @@ __global__ __launch_bounds__(256) void attn32_row_kernel(Attn32Args p) {
 
 // dK, dV: one wave per key row
 __global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32Args p) {
+  resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) float sm32[];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wib;  // (b*H + h)*T + key
@@ -1194,7 +1509,6 @@ int vit_attention_fwd(vit_handle h, const void* qkv, void* ctx, float* lse, int 
 
 int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo, float* lse, int io_dtype, int B, int H,
                          int T, int dh, float scale, float dropout_p, uint64_t seed, uint64_t site, vit_stream stream) {
-  (void)h;
   VIT_CHECK(qkv && ctx && lse, VIT_ERR_ARG, "vit_attention_fwd: null pointer");
   int rc = check_attn("vit_attention_fwd", B, H, T, dh, dropout_p);
   if (rc != VIT_OK) return rc;
@@ -1202,13 +1516,13 @@ int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo,
     Attn32Args a32 = {};
     a32.qkv = (const float*)qkv; a32.ctx = (float*)ctx; a32.lse = lse;
     a32.B = B; a32.H = H; a32.T = T; a32.dh = dh; a32.scale = scale;
-    a32.drop = make_drop(dropout_p, seed, site);
+    a32.drop = make_drop_h(h, dropout_p, seed, site);
     return launch_attn32(0, a32, (hipStream_t)stream);
   }
   AttnArgs a = {};
   a.qkv = (const short*)qkv; a.ctx = (short*)ctx; a.ctx_lo = (short*)ctx_lo; a.lse = lse;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
-  a.drop = make_drop(dropout_p, seed, site);
+  a.drop = make_drop_h(h, dropout_p, seed, site);
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     DISPATCH_RES(attn_fwd_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), (hipStream_t)stream, rc);
     return rc;
@@ -1250,7 +1564,8 @@ int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const v
     res_geometry(T, &nsplit, &wpw);
     size_t wsb = 0;
     float* part = (float*)ctx_workspace(h, &wsb);
-    const int prow = B * nsplit * wpw;
+    const bool fused = g_attn_bwd_fused && fused_fits(T, dh);  // one partial row per wave: 8 waves per (batch) there
+    const int prow = fused ? B * (g_attn_bwd_fused == 2 ? 16 : 8) : B * nsplit * wpw;
     if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
       // the resident kernels leave one partial row per wave: column sums of what they stored
       int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed,
@@ -1268,7 +1583,6 @@ int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const v
 static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, const void* ctx_lo, const void* dctx,
                               const float* lse, float* delta, void* dqkv, int io_dtype, int B, int H, int T, int dh,
                               float scale, float dropout_p, uint64_t seed, uint64_t site, float* colsum_part, vit_stream stream) {
-  (void)h;
   VIT_CHECK(qkv && ctx && dctx && lse && delta && dqkv, VIT_ERR_ARG, "vit_attention_bwd: null pointer");
   int rc = check_attn("vit_attention_bwd", B, H, T, dh, dropout_p);
   if (rc != VIT_OK) return rc;
@@ -1278,7 +1592,7 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
     a32.qkv = (const float*)qkv; a32.ctx = (float*)const_cast<void*>(ctx); a32.lse = const_cast<float*>(lse);
     a32.dctx = (const float*)dctx; a32.delta = delta; a32.dqkv = (float*)dqkv;
     a32.B = B; a32.H = H; a32.T = T; a32.dh = dh; a32.scale = scale;
-    a32.drop = make_drop(dropout_p, seed, site);
+    a32.drop = make_drop_h(h, dropout_p, seed, site);
     rc = launch_attn32(1, a32, st);
     if (rc != VIT_OK) return rc;
     return launch_attn32(2, a32, st);
@@ -1288,8 +1602,29 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.ctx_lo = (short*)const_cast<void*>(ctx_lo);
   a.dctx = (const short*)dctx; a.delta = delta; a.dqkv = (short*)dqkv;
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
-  a.drop = make_drop(dropout_p, seed, site);
+  a.drop = make_drop_h(h, dropout_p, seed, site);
   a.csum_part = colsum_part;
+  a.dbg = g_attn_debug;
+  if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
+    const size_t rows = (T + 15) & ~15;
+    const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 8);
+    const int nw = g_attn_bwd_fused == 2 ? 16 : 8;
+#define LAUNCH_FUSED(DH_, NW_)                                                                                           \
+  do {                                                                                                                   \
+    static bool attr = false;                                                                                            \
+    if (!attr) {                                                                                                         \
+      VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<DH_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  160 * 1024));                                                                          \
+      attr = true;                                                                                                       \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((attn_bwd_fused_kernel<DH_, NW_>), dim3(B * H), dim3(NW_ * 64), smem, st, a);                    \
+  } while (0)
+    if (dh <= 32) { if (nw == 16) LAUNCH_FUSED(32, 16); else LAUNCH_FUSED(32, 8); }
+    else { if (nw == 16) LAUNCH_FUSED(64, 16); else LAUNCH_FUSED(64, 8); }
+#undef LAUNCH_FUSED
+    VIT_LAUNCH_CHECK();
+    return VIT_OK;
+  }
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
@@ -1306,7 +1641,6 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
 
 int vit_attention_probs(vit_handle h, const void* qkv, float* probs, int io_dtype, int B, int H, int T, int dh,
                         float scale, vit_stream stream) {
-  (void)h;
   VIT_CHECK(qkv && probs, VIT_ERR_ARG, "vit_attention_probs: null pointer");
   int rc = check_attn("vit_attention_probs", B, H, T, dh, 0.f);
   if (rc != VIT_OK) return rc;

@@ -70,7 +70,16 @@ struct DropCfg {
   unsigned thr;   // 0 => dropout off
   float scale;    // 1/(1-p_eff)
   unsigned k0, k1;
+  // optional per-step keys in DEVICE memory (vit_step_state_bind): XORed into (k0, k1) at kernel entry, so a captured
+  // hipGraph draws fresh masks on every replay although its kernel arguments are frozen
+  const unsigned* dyn;
 };
+__device__ __forceinline__ void resolve_drop(DropCfg& d) {
+  if (d.thr && d.dyn) {
+    d.k0 ^= d.dyn[0];
+    d.k1 ^= d.dyn[1];
+  }
+}
 __host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint64_t site) {
   DropCfg d;
   unsigned thr = (p <= 0.f) ? 0u : (unsigned)(p * 65536.0f + 0.5f);
@@ -83,6 +92,7 @@ __host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint64_t si
   z ^= z >> 31;
   d.k0 = (unsigned)z;
   d.k1 = (unsigned)(z >> 32);
+  d.dyn = nullptr;
   return d;
 }
 // multiplier (0 or scale) for 2 adjacent columns starting at even column `col`
@@ -154,6 +164,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
 constexpr unsigned OOB = 0x80000000u;  // any voffset >= num_records reads as zero
+
+// the handle's bound per-step state (api.hip): [key0, key1, lr, bc1, rsqrt_bc2, step] in device memory, or NULL
+struct StepState { unsigned key0, key1; float lr, bc1, rsqrt_bc2; unsigned step; };
+const StepState* ctx_step_state(vit_handle h);
+static inline DropCfg make_drop_h(vit_handle h, float p, uint64_t seed, uint64_t site) {
+  DropCfg d = make_drop(p, seed, site);
+  const StepState* s = h ? ctx_step_state(h) : nullptr;
+  d.dyn = s ? &s->key0 : nullptr;
+  return d;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -42,6 +42,7 @@ __global__ void unfold_cast_kernel(const float* __restrict__ x, void* __restrict
 // ------------------------------------------------------------------------------------------ embedding finish
 __global__ void embed_finish_kernel(float* __restrict__ tok, const float* __restrict__ cls,
                                     const float* __restrict__ pos, int B, int T, int D, DropCfg drop) {
+  resolve_drop(drop);
   const int dv = D >> 2;
   const long total = (long)B * T * dv;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -66,6 +67,7 @@ __global__ void embed_finish_kernel(float* __restrict__ tok, const float* __rest
 template <int OUT_BF16>
 __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, void* __restrict__ dpatch,
                                         float* __restrict__ part, int B, int T, int D, DropCfg drop, int bchunk) {
+  resolve_drop(drop);
   // blockIdx.y walks a chunk of the batch; its (t, 4 columns) sums go to part[blockIdx.y][T*D] (reduced afterwards in a
   // fixed order: deterministic) -- one thread per (t, 4 columns) walking the WHOLE batch left 40 % of the CUs idle and
   // serialised 256 loads per thread (205 us at B = 256)
@@ -103,6 +105,7 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dtok, void* __
 template <int OUT_BF16>
 __global__ void dropout_bwd_cast_kernel(const float* __restrict__ dx, void* __restrict__ dy, long rows, int cols,
                                         DropCfg drop) {
+  resolve_drop(drop);
   const int cv = cols >> 2;
   const long total = rows * cv;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -272,6 +275,12 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ log
     __syncthreads();
   }
   if (threadIdx.x == 0) loss[0] = red[0] / (float)(kind == VIT_LOSS_CE ? B : B * C);
+}
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long nv = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x)
+    *(f32x4*)(p + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(nv << 2) + threadIdx.x] = 0.f;
 }
 // dlogits (workspace, [B,C]) and the CLS rows of d(last_hidden); one wave per sample
 __global__ __launch_bounds__(64) void head_bwd_rows_kernel(const float* __restrict__ W, const float* __restrict__ logits,
@@ -552,7 +561,7 @@ int vit_embed_finish(vit_handle h, float* tokens, const float* cls, const float*
   VIT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, VIT_ERR_ARG, "vit_embed_finish: dropout_p out of [0,1)");
   const long total = (long)B * T * (D / 4);
   hipLaunchKernelGGL(embed_finish_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, tokens, cls, pos, B,
-                     T, D, make_drop(dropout_p, seed, site));
+                     T, D, make_drop_h(h, dropout_p, seed, site));
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
@@ -571,10 +580,10 @@ int vit_embed_finish_bwd(vit_handle h, const float* dtokens, void* dpatch_out, i
   const dim3 grid(cdiv((long)T * (D / 4), 256), ny);
   if (dpatch_dtype == VIT_BF16)
     hipLaunchKernelGGL(embed_finish_bwd_kernel<1>, grid, dim3(256), 0, st, dtokens, dpatch_out, part, B, T, D,
-                       make_drop(dropout_p, seed, site), bchunk);
+                       make_drop_h(h, dropout_p, seed, site), bchunk);
   else
     hipLaunchKernelGGL(embed_finish_bwd_kernel<0>, grid, dim3(256), 0, st, dtokens, dpatch_out, part, B, T, D,
-                       make_drop(dropout_p, seed, site), bchunk);
+                       make_drop_h(h, dropout_p, seed, site), bchunk);
   VIT_LAUNCH_CHECK();
   // dcls = sum over the batch of row t = 0; dpos (if any) = the sums of every row
   int rc = launch_reduce_partials(part, ny, D, dcls, D, dcls, accumulate, st, T * D);
@@ -590,10 +599,10 @@ int vit_dropout_bwd_cast(vit_handle h, const float* dx, void* dy, int dy_dtype, 
   const long total = (long)rows * (cols / 4);
   if (dy_dtype == VIT_BF16)
     hipLaunchKernelGGL(dropout_bwd_cast_kernel<1>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, dy,
-                       (long)rows, cols, make_drop(dropout_p, seed, site));
+                       (long)rows, cols, make_drop_h(h, dropout_p, seed, site));
   else
     hipLaunchKernelGGL(dropout_bwd_cast_kernel<0>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dx, dy,
-                       (long)rows, cols, make_drop(dropout_p, seed, site));
+                       (long)rows, cols, make_drop_h(h, dropout_p, seed, site));
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }
@@ -654,7 +663,10 @@ int vit_head_loss_bwd(vit_handle h, const float* last_hidden, const float* W, co
   float* dlog = (float*)ctx_workspace(h, &wsb);
   VIT_CHECK(dlog && wsb >= (size_t)B * C * 4, VIT_ERR_WORKSPACE, "vit_head_loss_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  VIT_HIP(hipMemsetAsync(dlast_hidden, 0, (size_t)B * T * D * sizeof(float), st));
+  // a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node did not reliably run before the kernels that
+  // follow it (replays kept stale rows), and a fill kernel is ordered like every other node
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(grid_for((long)B * T * D / 4 + 1)), dim3(256), 0, st, dlast_hidden, (long)B * T * D);
+  VIT_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(B), dim3(64), 0, st, W, logits, labels, dloss, dlog, dlast_hidden, B, T,
                      D, C, loss_kind);
   VIT_LAUNCH_CHECK();
@@ -682,6 +694,81 @@ int vit_grad_sqnorm(vit_handle h, const float* g, int64_t n, float* out, vit_str
 }
 int vit_grad_sqnorm_acc(vit_handle h, const float* g, int64_t n, float* out, vit_stream stream) {
   return grad_sqnorm_impl(h, g, n, out, 1, stream);
+}
+
+// ---- per-step state in device memory (hipGraph replays): one thread advances the step counter and derives from it the
+// dropout keys of the step and AdamW's bias corrections; lr is whatever the host last wrote into the state
+__global__ void step_advance_kernel(StepState* s, unsigned long long base_seed, float b1, float b2) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned step = s->step + 1;
+    unsigned long long z = base_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)step;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    s->key0 = (unsigned)z;
+    s->key1 = (unsigned)(z >> 32);
+    // in double, like the host computes them for the eager vit_adamw_step: graph and eager steps stay bit-identical
+    s->bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    s->rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)step)));
+    s->step = step;
+  }
+}
+__global__ __launch_bounds__(256) void adamw_dyn_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        short* __restrict__ pb, long n, const StepState* __restrict__ st,
+                                                        float b1, float b2, float eps, float wd,
+                                                        const float* __restrict__ sqnorm, float max_norm) {
+  float clip = 1.f;
+  if (sqnorm) clip = fminf(1.f, max_norm / (sqrtf(sqnorm[0]) + 1e-6f));
+  const float lr = st->lr, rsqrt_bc2 = st->rsqrt_bc2;
+  const float step = lr / st->bc1, decay = 1.f - lr * wd;
+  const long nv = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = *(const f32x4*)(p + 4 * i);
+    const f32x4 gg = *(const f32x4*)(g + 4 * i) * clip;
+    f32x4 mm = *(const f32x4*)(m + 4 * i);
+    f32x4 vv = *(const f32x4*)(v + 4 * i);
+    mm = mm * b1 + gg * (1.f - b1);
+    vv = vv * b2 + gg * gg * (1.f - b2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pp[k] = pp[k] * decay - step * mm[k] / (sqrtf(vv[k]) * rsqrt_bc2 + eps);
+    *(f32x4*)(p + 4 * i) = pp;
+    *(f32x4*)(m + 4 * i) = mm;
+    *(f32x4*)(v + 4 * i) = vv;
+    if (pb) {
+      u32x2 pk = {pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
+      *(u32x2*)(pb + 4 * i) = pk;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (nv << 2) + threadIdx.x;
+    const float gg = g[i] * clip;
+    const float mm = m[i] * b1 + gg * (1.f - b1);
+    const float vv = v[i] * b2 + gg * gg * (1.f - b2);
+    const float pp = p[i] * decay - step * mm / (sqrtf(vv) * rsqrt_bc2 + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f2bf(pp);
+  }
+}
+
+int vit_step_advance(vit_handle h, uint64_t base_seed, float beta1, float beta2, vit_stream stream) {
+  const StepState* st = ctx_step_state(h);
+  VIT_CHECK(st, VIT_ERR_ARG, "vit_step_advance: no step state bound (vit_step_state_bind)");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, const_cast<StepState*>(st),
+                     (unsigned long long)base_seed, beta1, beta2);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_adamw_step_dyn(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1,
+                       float beta2, float eps, float weight_decay, const float* sqnorm, float max_norm, vit_stream stream) {
+  const StepState* st = ctx_step_state(h);
+  VIT_CHECK(st, VIT_ERR_ARG, "vit_adamw_step_dyn: no step state bound (vit_step_state_bind)");
+  VIT_CHECK(p && g && m && v && n > 0, VIT_ERR_ARG, "vit_adamw_step_dyn: bad arguments");
+  hipLaunchKernelGGL(adamw_dyn_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (short*)p_bf16, (long)n, st, beta1, beta2, eps, weight_decay, sqnorm, max_norm);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
 }
 
 int vit_adamw_step(vit_handle h, float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,

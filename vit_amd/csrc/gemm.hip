@@ -166,6 +166,7 @@ struct Loader {
 
 template <int A_T, int B_T>
 __global__ __launch_bounds__(NTHR, 2) void gemm_bf16_kernel(GemmArgs p) {
+  resolve_drop(p.drop);
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -325,6 +326,7 @@ __device__ __forceinline__ void split8(const i32x4& v0, const i32x4& v1, i32x4& 
 
 template <int A_T, int B_T>
 __global__ __launch_bounds__(NTHR, 2) void gemm_f32x3_kernel(GemmArgs p) {
+  resolve_drop(p.drop);
   __shared__ __attribute__((aligned(16))) char smem[2 * XSTAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -559,7 +561,7 @@ static int gemm_launch_core(vit_handle h, const vit_gemm_desc* d, hipStream_t st
   }
   a.alpha = d->alpha;
   a.act = d->act; a.c_dtype = d->c_dtype;
-  a.drop = make_drop(d->dropout_p, d->seed, d->site);
+  a.drop = make_drop_h(h, d->dropout_p, d->seed, d->site);
   if (a.drop.thr) VIT_CHECK((d->N % 2) == 0, VIT_ERR_ARG, "vit_gemm: dropout needs an even N");
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
 

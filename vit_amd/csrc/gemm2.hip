@@ -50,6 +50,7 @@ struct Gemm2Args {
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
   int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
   int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
+  int grp2;  // ping-pong kernel: XCDs 0-3 walk the lower half of the N-tiles, XCDs 4-7 the upper half (see tile_coords)
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
@@ -164,6 +165,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[WM][WN], char* scr, c
 // each), so one workgroup's epilogue / DMA waits overlap the other's MFMAs.
 template <int BM, int BN, int BK, int NSTAGE, int NW, int A_T, int B_T, int EPI>
 __global__ __launch_bounds__(NW * 64, 2) void gemm2_kernel(Gemm2Args p) {
+  resolve_drop(p.drop);
   constexpr int WAVES_N = (NW == 8 && BN == 256) ? 4 : 2, WAVES_M = NW / WAVES_N;
   constexpr int LDS_TOTAL = (NW == 8) ? 160 * 1024 : 80 * 1024;
   constexpr int RND = NW * 1024;  // bytes one DMA round (one instruction per wave) moves
@@ -501,6 +503,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
 // epilogue's >= 32 stores per wave into the vmcnt budget instead of draining them.
 template <int A_T, int B_T, int EPI, int NSLOT>
 __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
+  resolve_drop(p.drop);
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * BK * 2;     // one half-tile image: 16 KiB
   // NSLOT half-tile slots, stream index h lives in slot h % NSLOT and is issued in phase h - DEPTH, DEPTH = NSLOT - 3 (the
@@ -571,6 +574,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     const int n_here = min(nblk, ntile - round0);
     const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
     const int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    if (p.grp2) {
+      // N = 3072 (12 tiles): the B operand (4.7 MB of weights) does not fit an XCD's 4 MiB L2, and with every XCD walking
+      // all 12 N-tiles each round it was re-fetched per XCD per round (PMC: 482 MB read against an 82 MB operand set).
+      // Split the N-tiles in two halves of 2.4 MB: the first half of a round's positions (XCDs 0-3) keeps walking the lower
+      // half, the second (XCDs 4-7) the upper half, M-panel by M-panel, so each XCD's weights stay L2-resident across
+      // rounds and an A panel is fetched by two XCD groups instead of ~1.3 -- 393 KB more per panel against 4.7 MB less per
+      // XCD-round.  nblk and the tile count are even (host), so each round splits exactly and the map is a bijection.
+      const int hgrp = n_here >> 1, hn = p.tiles_n >> 1;
+      const int g = pos >= hgrp;
+      const int u = (round0 >> 1) + (g ? pos - hgrp : pos);
+      tm = u / hn;
+      tn = g * hn + (u - tm * hn);
+      return;
+    }
     const int t = p.lin_split ? bx : round0 + pos;
     tm = t / p.tiles_n;
     tn = t - tm * p.tiles_n;
@@ -754,6 +771,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 // flight at every wait.  A separate code object on purpose: the main kernel's register allocation is untouched.
 template <int A_T, int B_T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
+  resolve_drop(p.drop);
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * BK * 2, NSLOT = 8;
   constexpr int SCR = 4096, CW = 64;
@@ -922,6 +940,7 @@ static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
   return launch_half<0, 1, 6>(a, st);
 }
 
+int g_grp2 = 1;  // vit_set_option("gemm_ngroups"): 1 = two N-groups for weights larger than an L2 (see tile_coords)
 int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
 int g_pp_slots = 8;  // vit_set_option("gemm_pp_slots"): half-tile slots of the ping-pong ring, 8 (default) or 10
@@ -1035,7 +1054,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   }
   a.alpha = d->alpha;
   a.act = d->act; a.c_dtype = d->c_dtype;
-  a.drop = make_drop(d->dropout_p, d->seed, d->site);
+  a.drop = make_drop_h(h, d->dropout_p, d->seed, d->site);
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
   a.debug = g_gemm2_debug;
 
@@ -1068,6 +1087,15 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     // just enough workgroups for that many rounds: the idle CUs' power budget goes to the busy ones' clock
     a.nblk = cdiv(ntile - half_tail, cdiv(ntile - half_tail, slots));
     grid = dim3(a.nblk, splits);
+  }
+  a.grp2 = 0;
+  if (cfg == 5 && g_grp2 && splits == 1 && !half_tail && !a.lin_split && (a.tiles_n % 2) == 0 &&
+      (size_t)d->N * d->K * 2 > (size_t)4 << 20 && ntile > slots && (ntile % 2) == 0) {
+    a.grp2 = 1;
+    if (a.nblk & 1) {  // each round must split into two equal halves
+      a.nblk += 1;
+      grid = dim3(a.nblk, splits);
+    }
   }
   if (half_tail) {
     a.tile_limit = ntile - half_tail;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part, int rows, int D,
                                                      void* __restrict__ dyn, DropCfg drop) {
+  resolve_drop(drop);
   constexpr int NP = FUSE ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][D]
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -294,7 +295,7 @@ int vit_layernorm_bwd_fused(vit_handle h, const void* dy, int dy_dtype, const fl
   VIT_CHECK(rows > 0 && D > 0 && (D % 4) == 0, VIT_ERR_ARG, "vit_layernorm_bwd_fused: rows=%d D=%d", rows, D);
   VIT_CHECK(dropout_p >= 0.f && dropout_p < 1.f, VIT_ERR_ARG, "vit_layernorm_bwd_fused: dropout_p out of [0,1)");
   return ln_bwd_common(h, dy, dy_dtype, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, dyn, dyn_dtype, dbias,
-                       make_drop(dropout_p, seed, site), (hipStream_t)stream);
+                       make_drop_h(h, dropout_p, seed, site), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -144,6 +144,9 @@ class Trainer:
         self.device = device or torch.device("cuda", self.local_rank)
         self.backend = torch.distributed.get_backend() if self.world > 1 else None
         self.exchange = str(config.get("ddp_exchange", os.environ.get("VIT_DDP_EXCHANGE", "allreduce")))
+        # train.hip_graph: replay the optimisation step as one captured hipGraph (vit_amd/graph.py; single GPU only)
+        self.use_graph = bool(config.get("hip_graph", False))
+        self._graphed = None
         self.verbose = verbose and self.rank == 0
         self.logged: Dict[str, float] = {}
         self.metric_totals: Dict[str, float] = {}
@@ -227,6 +230,8 @@ class Trainer:
     def training_step(self, module, batch, batch_idx):
         """zero_grad -> forward -> backward (+ overlapped gradient exchange) -> clip -> optimizer step."""
         self._cur_bs = _batch_size(batch)
+        if self.use_graph and self.world == 1:
+            return self._graph_step(module, batch)
         self.optimizer.zero_grad(set_to_none=True)
         loss = module.training_step(batch, batch_idx)
         loss.backward()
@@ -239,6 +244,19 @@ class Trainer:
         if not isinstance(self.optimizer, FusedAdamW) and self.gradient_clip_val:
             torch.nn.utils.clip_grad_norm_([p for p in module.parameters() if p.grad is not None], self.gradient_clip_val)
         self.optimizer.step()
+        if self.sched_cfg and self.sched_cfg.get("interval") == "step":
+            self.sched_cfg["scheduler"].step()
+        self.global_step += 1
+        return loss
+
+    def _graph_step(self, module, batch):
+        from .graph import GraphedTrainStep
+
+        g = self._graphed
+        if g is None or g.x.shape != batch[0].shape or g.eng.precision != module.model.engine.precision:
+            g = self._graphed = GraphedTrainStep(module, self.optimizer, batch)  # capture (runs warm-up steps on this batch)
+        loss = g.step(batch)
+        module.log(f"{module.loss_name}_loss", loss, on_step=True, on_epoch=True, prog_bar=True)
         if self.sched_cfg and self.sched_cfg.get("interval") == "step":
             self.sched_cfg["scheduler"].step()
         self.global_step += 1
