@@ -90,6 +90,7 @@ def main():
                     help="bf16-mixed = the BASELINE.json metric; 32 = the fp32-class mode (x3 GEMMs), for the record only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
+    ap.add_argument("--no-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (no second HIP stream)")
     ap.add_argument("--no-graph", action="store_true",
                     help="N = 1: launch the step's kernels eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
@@ -142,6 +143,8 @@ def main():
     trainer = Trainer(config["train"], device=dev, verbose=False)
     trainer._setup(module)
     module.train()
+    if args.no_overlap:
+        module.model.engine.overlap_dw = False
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     flux = torch.randn((B, L), generator=g).to(dev)
@@ -177,7 +180,15 @@ def main():
     if rank == 0:
         log(f"model on {dev}, {sum(p.numel() for p in module.parameters())} parameters; warm-up {args.warmup} steps")
     for i in range(args.warmup):
-        trainer.training_step(module, batch, i)
+        try:
+            trainer.training_step(module, batch, i)
+        except Exception as e:  # noqa: BLE001 - the harness must still produce its line: capture trouble -> eager launches
+            if not (use_graph and i == 0):
+                raise
+            log(f"hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches")
+            use_graph = trainer.use_graph = False
+            torch.cuda.synchronize()
+            trainer.training_step(module, batch, i)
     torch.cuda.synchronize()
     if rank == 0:
         log(f"timing {args.steps} steps")
@@ -195,6 +206,9 @@ def main():
         n_inst = min(args.steps, 20)
         timing_on[0] = True
         trainer.use_graph = False  # the per-GEMM event brackets need the eager launches
+        # ... and each GEMM alone on the GPU: with the weight-gradient GEMMs on their second stream a bracket would time two
+        # kernels sharing the CUs, not a launch
+        module.model.engine.overlap_dw = False
         barrier()
         t1 = time.perf_counter()
         for i in range(n_inst):

@@ -377,3 +377,36 @@ def test_hip_graph_step_equals_eager(dev, precision):
     b = tuple(t.cuda() for t in batches[0])
     seen = {round(float(trainer.training_step(module, b, i)), 7) for i in range(4)}
     assert len(seen) == 4, seen
+
+
+def test_cli_run_save_then_test_only(dev, tmp_path):
+    """`launch.sh run --save` then `launch.sh test --ckpt last` (scripts/run.py, scripts/test.py): the test entry evaluates the
+    checkpoint without training (reference: scripts/test.py:26-48) and reports the same test metrics the run
+    printed after its own fit."""
+    import re
+    import subprocess
+    import sys
+
+    import yaml
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = c1_config(ep=2, precision="bf16-mixed")
+    cfg["project"] = "t"
+    path = tmp_path / "c.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    env = dict(os.environ, CKPT_DIR=str(tmp_path / "ck"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r1 = subprocess.run(["bash", os.path.join(root, "launch.sh"), "run", "-c", str(path), "-g", "1", "--save", "--synthetic", "256"],
+                        capture_output=True, text=True, env=env, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert sorted(f for f in os.listdir(tmp_path / "ck") if f.endswith(".ckpt"))[-1] == "last.ckpt"
+    m1 = dict(re.findall(r"(test_\w+)=([-\d.e+]+)", [l for l in r1.stdout.splitlines() if l.startswith("[test] ")][-1]))
+    r2 = subprocess.run(["bash", os.path.join(root, "launch.sh"), "test", "-c", str(path), "-g", "1", "--ckpt", "last", "--synthetic", "256"],
+                        capture_output=True, text=True, env=env, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "[epoch" not in r2.stdout  # nothing was trained
+    m2 = dict(re.findall(r"(test_\w+)=([-\d.e+]+)", [l for l in r2.stdout.splitlines() if l.startswith("[test] ") and "=" in l][-1]))
+    assert m1.keys() == m2.keys() and "test_mae" in m1
+    for k in m1:
+        assert abs(float(m1[k]) - float(m2[k])) <= 1e-4 * max(1.0, abs(float(m1[k]))), (k, m1[k], m2[k])

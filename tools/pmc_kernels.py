@@ -2,7 +2,9 @@
 """Per-kernel averages of rocprofv3 PMC passes (one directory per pass, each a separate run with --kernel-trace --pmc ...
 --output-format csv, never combined with other trace domains), merged into one JSON with derived figures:
 
-  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x 4 SIMDs)        (north_star's "MFMA utilisation")
+  mfma_util      = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) x CUs x 4 SIMDs)   (north_star's "MFMA utilisation";
+                   rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs: 7.8 M "cycles" for a 450 us kernel at
+                   2.2 GHz -- checked against duration x clock and against FLOP / time: dW GEMM 0.34 vs 817 TFLOP/s / 2.5 P)
   wave-cycle split: active = SQ_ACTIVE_INST_ANY, issue-stall = SQ_WAIT_INST_ANY, parked = SQ_WAIT_ANY, each / SQ_WAVE_CYCLES
   hbm_bytes      = 2 x FETCH_SIZE KiB (gfx950: wide reads are half-counted) + WRITE_SIZE KiB     (MI355X_MICROARCH.md)
   l2_hit         = TCC_HIT / (TCC_HIT + TCC_MISS)
@@ -36,7 +38,7 @@ def main():
         c = {k: acc[name][k] / cnt[name][k] for k in acc[name]}
         e = {"launches": max(cnt[name].values()), "counters": {k: round(v, 1) for k, v in sorted(c.items())}}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
-            e["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * cus * 4), 4)
+            e["mfma_util"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * cus * 4), 4)
         wc = c.get("SQ_WAVE_CYCLES")
         if wc:
             for key, ctr in (("active", "SQ_ACTIVE_INST_ANY"), ("issue_stall", "SQ_WAIT_INST_ANY"), ("parked", "SQ_WAIT_ANY"),

@@ -149,6 +149,10 @@ class ViTEngine:
         self.base_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
         self.step_counter = 0
         self._last = None
+        # weight-gradient GEMMs on a second HIP stream (see _dw): None = off
+        self.side_stream: Optional[torch.cuda.Stream] = None
+        self._side_handle = None
+        self.overlap_dw = True
         self._gen = 0  # bumped by every forward: the activation arena holds ONE forward, backward checks it is still that one
         self.grad_ready_cb: Optional[Callable[[int, int], None]] = None
         # Parameters are views of `flat` with their OWN version counters (nn.Parameter / .data re-pointing do not share
@@ -406,6 +410,37 @@ class ViTEngine:
         vf.layernorm_fwd_residual(x, delta, xsum, self.p(name + ".weight"), self.p(name + ".bias"),
                                   self.cfg.layer_norm_eps, out=out, mean=mean, rstd=rstd)
 
+    # ------------------------------------------------------------------ weight gradients beside the data path
+    def _dw(self, *args, **kw):
+        """A weight-gradient GEMM (dW = dY^T X, deterministic split-K).  Its only consumer is the optimizer at the end of the
+        step, so it is enqueued on a second HIP stream (own vit_handle = own split-K workspace) right after its operands are
+        complete, and runs beside the dX GEMM / attention kernels that continue the chain on the main stream: the 256-CU
+        rounds of one kernel leave holes (N = 768 GEMMs: 2.31 rounds; every kernel's ramp and drain) that the other
+        stream's workgroups fill.  `_join_side()` brings the streams together before anything overwrites an operand a
+        pending dW still reads (the next LayerNorm backward rewrites dy) and before the gradients are consumed."""
+        if self.side_stream is None:
+            return vf.gemm(*args, **kw)
+        main = torch.cuda.current_stream(self.flat.device)
+        self.side_stream.wait_stream(main)
+        with torch.cuda.stream(self.side_stream), vf.use_handle(self._side_handle):
+            return vf.gemm(*args, **kw)
+
+    def _join_side(self):
+        if self.side_stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.side_stream)
+
+    def _setup_side(self):
+        from . import _cabi
+
+        on = self.overlap_dw and self.precision == "bf16"
+        if on and self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.flat.device)
+            if self._side_handle is None:
+                self._side_handle = _cabi.Handle(self.flat.device.index if self.flat.device.index is not None
+                                                 else torch.cuda.current_device())
+        elif not on:
+            self.side_stream = None
+
     # ------------------------------------------------------------------ backward
     def backward(self, dloss: torch.Tensor, need_dx: bool = False, gen: Optional[int] = None):
         """Fill self.grads (every trainable slice exactly once) for the last forward; calls grad_ready_cb(lo, hi) as
@@ -433,6 +468,7 @@ class ViTEngine:
 
         vf.head_loss_bwd(a["last"], self.p(hn + ".weight"), st["logits"], st["labels"], dloss, self.loss_kind,
                          dlast=t["dlast"], dW=self.g(hn + ".weight"), db=self.g(hn + ".bias"))
+        self._setup_side()
         dx, dx_other = t["dxa"], t["dxb"]
         # every LayerNorm backward below also emits dy = dropout_mask * dx (bf16) and its column sums: the gradient of
         # the Linear output underneath the next "dropout(.) + residual" going down, and that Linear's bias gradient
@@ -450,21 +486,22 @@ class ViTEngine:
         for i in reversed(range(L)):
             pre = f"vit.encoder.layer.{i}."
             # x2 = dropout(g W2^T + b2) + x1      (t["dy"] = mask * dx and db2 were produced by the LN backward above)
-            vf.gemm(t["dy"], a["g"][i], M=D, N=Fd, K=Mp, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
-                    split_k=-1)
+            self._dw(t["dy"], a["g"][i], M=D, N=Fd, K=Mp, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
+                     split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=Mp, N=Fd, K=D, b_trans=True, out=t["dU"],
                     act=vf.ACT_MUL_AUX, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
-            vf.gemm(t["dU"], a["h2"][i], M=Fd, N=D, K=Mp, a_trans=True, b_trans=True,
-                    out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
+            self._dw(t["dU"], a["h2"][i], M=Fd, N=D, K=Mp, a_trans=True, b_trans=True,
+                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
             vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=D, K=Fd, b_trans=True, out=t["dh"])
             # x1 = dropout(ctx Wo^T + bo) + x:  LN2 backward -> dx1, and dya = mask * dx1 with dbo
+            self._join_side()  # the pending dW GEMMs read t["dy"], which this pass rewrites
             vf.layernorm_bwd_fused(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i],
                                    a["rstd2"][i], dx, dx_other, self.g(pre + "layernorm_after.weight"),
                                    self.g(pre + "layernorm_after.bias"), t["dy"],
                                    self.g(pre + "attention.output.dense.bias"), (ph, seed, self._site(i, 1)))
             dx, dx_other = dx_other, dx
-            vf.gemm(t["dy"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
-                    out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
+            self._dw(t["dy"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
+                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
             vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, b_trans=True, out=t["dctx"])
             # the QKV bias gradient = column sums of dqkv: taken by the attention kernels on their way out, unless RoPE
             # sits in between (then after the inverse rotation, by the column-sum kernel)
@@ -474,9 +511,10 @@ class ViTEngine:
             if rope is not None:  # gradient wrt the un-rotated q, k: the inverse rotation
                 vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
                 vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
-            vf.gemm(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
-                    split_k=-1)
+            self._dw(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
+                     split_k=-1)
             vf.gemm(t["dqkv"], self._qkv16(i), M=Mp, N=D, K=3 * D, b_trans=True, out=t["dh"])
+            self._join_side()  # dW(out-proj) read t["dy"], dW(qkv) reads t["dqkv"]; the gradients of this layer complete
             if i > 0:
                 # LN1 backward -> dx (input of this layer = output of layer i-1), plus layer i-1's FC2 pieces
                 prev = f"vit.encoder.layer.{i - 1}."
@@ -498,6 +536,7 @@ class ViTEngine:
         vf.colsum(t["dpatch"], out=self.g(e + "patch_embeddings.projection.bias"))
         vf.gemm(t["dpatch"], a["patches"], M=D, N=P, K=B * N, a_trans=True, b_trans=True,
                 out=self.g(e + "patch_embeddings.projection.weight").view(D, P), split_k=-1)
+        self._join_side()
         if cb:
             cb(self.layout.embed_start, self.layout.embed_end)
         if need_dx:

@@ -17,10 +17,31 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_HANDLE_OVERRIDE: Optional[_cabi.Handle] = None
+
+
 def _h(t: torch.Tensor) -> _cabi.Handle:
     if not t.is_cuda:
         raise _cabi.VitError("vit_amd kernels need tensors on an MI355X (cuda/hip device); there is no CPU path")
-    return _cabi.handle_for(t.device)
+    return _HANDLE_OVERRIDE if _HANDLE_OVERRIDE is not None else _cabi.handle_for(t.device)
+
+
+class use_handle:
+    """Route the calls inside the block through another vit_handle (its own workspace): what runs concurrently on a second
+    HIP stream must not share split-K slabs / reduction partials with the main stream's kernels."""
+
+    def __init__(self, handle: _cabi.Handle):
+        self.handle = handle
+
+    def __enter__(self):
+        global _HANDLE_OVERRIDE
+        self.prev, _HANDLE_OVERRIDE = _HANDLE_OVERRIDE, self.handle
+        return self.handle
+
+    def __exit__(self, *exc):
+        global _HANDLE_OVERRIDE
+        _HANDLE_OVERRIDE = self.prev
+        return False
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
