@@ -719,7 +719,8 @@ def test_attention_delta_residual(dev, B, H, T, dh):
     assert max(e1) < 1.5e-2, e1
 
 
-@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 197, 64), (1, 2, 224, 64), (1, 2, 240, 32), (3, 1, 17, 64), (1, 2, 64, 64)])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 197, 64), (1, 2, 224, 64), (1, 2, 240, 32), (3, 1, 17, 64), (1, 2, 64, 64),
+                                      (40, 12, 197, 64), (300, 1, 130, 64)])  # the last two: several heads per persistent workgroup
 @pytest.mark.parametrize("drop", [(0.0, 0, 0), (0.1, 7, 5)])
 def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     """The single-kernel backward (one workgroup per head; dS through the LDS) against the dQ + dK/dV pair: same dropout
@@ -735,17 +736,18 @@ def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     dctx = bf(randn((B * T, H * dh), dev, 71))
     out = {}
     try:
-        for fused in (0, 1, 2):  # two-kernel path, fused with 8 waves, fused with 16 waves
+        for fused in (0, 1, 2, 3):  # two-kernel path, fused with 8 / 16 waves, persistent pipelined form (dh = 64, T <= 224)
             _cabi.set_option("attn_bwd_fused", fused)
             cs = torch.zeros(3 * H * dh, device=dev)
             delta = torch.zeros((B * H, T), device=dev)
             d = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale, dropout=drop, colsum_out=cs, ctx_lo=lo, delta=delta)
             out[fused] = (d.clone(), cs.clone(), delta.clone())
     finally:
-        _cabi.set_option("attn_bwd_fused", 1)
+        _cabi.set_option("attn_bwd_fused", 3)
     a, b_ = out[0], out[1]
-    assert rel(out[2][0], a[0]) < 6e-3 and rel(out[2][2], a[2]) < 1e-5
-    assert rel(out[2][1], out[2][0].float().sum(0)) < 1e-5
+    for k in (2, 3):
+        assert rel(out[k][0], a[0]) < 6e-3 and rel(out[k][2], a[2]) < 1e-5, k
+        assert rel(out[k][1], out[k][0].float().sum(0)) < 1e-5, k
     assert rel(b_[0], a[0]) < 6e-3, rel(b_[0], a[0])
     assert rel(b_[2], a[2]) < 1e-5
     assert rel(b_[1], b_[0].float().sum(0)) < 1e-5  # column sums of what was stored

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing decomposition of the fused attention backward by skipping pieces (vit_set_option("attn_debug"); results invalid)."""
+"""Timing decomposition of the fused / persistent attention backward by skipping pieces (vit_set_option("attn_debug"))."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,7 @@ def t(fn, n=10):
     return e0.elapsed_time(e1) / n * 1e3
 sc = dh ** -0.5
 vf.attention_fwd(qkv, B, H, T, dh, sc, dropout=(0.1, 1, 2), ctx=ctx, lse=lse, ctx_lo=lo)
-for fused in (1, 2):
+for fused in (1, 3):
     _cabi.set_option("attn_bwd_fused", fused)
     for dp in ((0.1, 1, 2), (0.0, 0, 0)):
         row = []
@@ -31,5 +31,6 @@ for fused in (1, 2):
             row.append((dbg, t(lambda: vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, sc, dropout=dp, dqkv=dqkv, delta=delta,
                                                         colsum_out=cs, ctx_lo=lo))))
         _cabi.set_option("attn_debug", 0)
-        print(f"fused{8 * fused} dropout {dp[0]}: " + "  ".join(f"dbg{d}={v:.0f}" for d, v in row), flush=True)
+        print(f"mode{fused} dropout {dp[0]}: " + "  ".join(f"dbg{d}={v:.0f}" for d, v in row), flush=True)
 print("dbg bits: 1 = no phase B, 2 = no phase A, 4 = no Q/dO/K staging, 8 = no dK/dV stores")
+_cabi.set_option("attn_bwd_fused", 3)

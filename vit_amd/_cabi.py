@@ -120,6 +120,12 @@ def load():
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = lib
+        # VIT_OPTIONS="name=value,name=value": kernel-selection knobs of vit_set_option for A/B runs of unmodified scripts
+        for item in filter(None, os.environ.get("VIT_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            rc = lib.vit_set_option(name.strip().encode(), int(value))
+            if rc != VIT_OK:
+                raise VitError(f"VIT_OPTIONS: vit_set_option({name!r}, {value}) failed: {lib.vit_last_error().decode()}")
         return lib
 
 

@@ -1256,8 +1256,317 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
   }
 }
 
+// ======================================================================================= persistent fused backward
+// The fused kernel above spends about half of its time outside the two compute phases: one workgroup per CU means the
+// global loads of a head, its compute and its stores run one after the other, and every head pays a workgroup launch.
+// This form keeps ONE workgroup per CU alive over its share of the heads and pipelines across (head, half) units:
+//   * Q / dO arrive by LDS-DMA (global_load_lds, no registers) one unit ahead, into the other of two 32 KiB buffers that
+//     each hold the 128 query rows of a half (the DMA writes 1 KiB of consecutive LDS per wave-instruction, so the XOR
+//     swizzle of the image is applied to the GLOBAL address of each lane);
+//   * the next head's K image is issued as soon as phase B of the current head has released it and lands during the next
+//     phase A; the next head's K / V rows (registers, dead outside phase A) and the O / O_lo / dO chunks of its delta
+//     pre-pass are issued before the last phase B and consumed after it.
+// Rows past T are clamped to row T - 1 instead of zero-filled (a DMA has no bounds check): their probabilities are 0 through
+// lse = +inf (queries) or a -inf added to the exponent (keys), so nothing depends on what the duplicate rows hold.
+// dh == 64 only (ViT-B / ViT-L); T <= 224 (LDS: 64 KiB of Q / dO buffers + K + a 128-query dS image + statistics).
+#define GLB_AS __attribute__((address_space(1)))
+
+__device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, int row0, int nrows_img, int T, int wave,
+                                           int lane) {
+  // image = nrows_img rows of 128 B, tile layout (row r at r * 128, chunk c at ((c ^ swz(r)) << 4))
+  const int p = lane & 7;
+  for (int j = wave; j < (nrows_img >> 3); j += 8) {
+    const int r = (j << 3) + (lane >> 3);
+    const int c = p ^ swz<64>(r & 63);
+    const int grow = min(row0 + r, T - 1);
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(g + (long)grow * ld + c * 8), (LDS_AS void*)(img + j * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DH = 64, NW = 8, TILE = RT * DH * 2, HALFB = 128 * DH * 2, RQ = 2, CPR = 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int T = p.T, BH = p.B * p.H;
+  const long ld = 3L * p.H * DH, ldc = (long)p.H * DH;
+  const int R = (T + 15) & ~15;
+  const int nq = R >> 4, npairs = (nq + 1) >> 1, nks = (T + 31) >> 5, nhalves = npairs > 4 ? 2 : 1;
+  char* QD = smem;                      // two buffers of [Q half | dO half]
+  char* Kimg = smem + 4 * HALFB;
+  char* dSimg = Kimg + R * (DH * 2);
+  float* stats = (float*)(dSimg + R * DSP);  // two sets of [lse | delta], R floats each: heads alternate
+  const float c = p.scale * LOG2E;
+  const unsigned half_cols = (unsigned)((T + 1) >> 1);
+  const int k00 = wave * RQ * 16;
+  const int dch = lane % CPR;
+
+  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
+
+  const long HD = (long)p.H * DH;
+  auto qoff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ld + (long)(bh - b * p.H) * DH; };
+  auto coff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ldc + (long)(bh - b * p.H) * DH; };
+  auto issue_half = [&](char* buf, int bh, int half) {
+    if (!(p.dbg & 4)) {
+      dma_rows64(buf, p.qkv + qoff_of(bh), ld, half * 128, 128, T, wave, lane);
+      dma_rows64(buf + HALFB, p.dctx + coff_of(bh), ldc, half * 128, 128, T, wave, lane);
+    }
+  };
+  auto issue_k = [&](int bh) {
+    if (!(p.dbg & 4)) dma_rows64(Kimg, p.qkv + qoff_of(bh) + HD, ld, 0, R, T, wave, lane);
+  };
+  auto issue_regs = [&](int bh) {  // this wave's K / V rows of head bh
+    const short* kb_ = p.qkv + qoff_of(bh) + HD;
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+      load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, DH, l15, lg);
+      load_own<DH>(vf[rq], kb_ + HD, ld, k00 + rq * 16, T, DH, l15, lg);
+    }
+  };
+  // delta[q] = sum_d dO (O + O_lo) and lse (exp2 domain) of head bh into statistics set `st`, rows row0, row0 + step, ...
+  // (8 lanes per row).  The first head: all waves; every later head: wave 7 alone, which owns no keys at T <= 224 and
+  // would otherwise idle through phase A -- it works one head ahead into the other statistics set.
+  // delta[q] = sum_d dO (O + O_lo) and lse (exp2 domain) of head bh, rows [row_lo, row_hi) (at most 128: two 8-row groups per
+  // wave), into statistics set `st`.  Split in two so the loads can be issued before a phase B and consumed after it.
+  i32x4 o4[2], d4[2], l4[2];
+  auto delta_issue = [&](int bh, int row_lo, int row_hi) {
+    const long co = coff_of(bh);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
+      o4[i] = d4[i] = l4[i] = (i32x4){0, 0, 0, 0};
+      if (row < T && row < row_hi) {
+        const long e0 = co + (long)row * ldc + dch * 8;
+        o4[i] = *(const i32x4*)(p.ctx + e0);
+        d4[i] = *(const i32x4*)(p.dctx + e0);
+        if (p.ctx_lo) l4[i] = *(const i32x4*)(p.ctx_lo + e0);
+      }
+    }
+  };
+  auto delta_finish = [&](int bh, float* st, int row_lo, int row_hi) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
+      const bf16x8 o8 = __builtin_bit_cast(bf16x8, o4[i]), d8 = __builtin_bit_cast(bf16x8, d4[i]);
+      const bf16x8 l8 = __builtin_bit_cast(bf16x8, l4[i]);
+      float d_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(d8[e]);
+#pragma unroll
+      for (int m = 1; m < CPR; m <<= 1) d_ += __shfl_xor(d_, m, 64);
+      if (dch == 0 && row < row_hi && row < R) {
+        st[R + row] = row < T ? d_ : 0.f;
+        st[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;  // (prefetching it with the chunks cost 4 spills: slower)
+        if (row < T) p.delta[(long)bh * T + row] = d_;
+      }
+    }
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= BH) return;
+  // ---- prologue: first unit's operands, first head's K image, registers and statistics
+  issue_half(QD, bh, 0);
+  issue_k(bh);
+  issue_regs(bh);
+  for (int r0 = 0; r0 < R; r0 += 128) {
+    delta_issue(bh, r0, min(R, r0 + 128));
+    delta_finish(bh, stats, r0, min(R, r0 + 128));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int u = 0, hidx = 0;
+  for (; bh < BH; bh += gridDim.x, ++hidx) {
+    const int bh_next = bh + gridDim.x;
+    const float* lse_s = stats + (hidx & 1) * (2 * R);
+    const float* del_s = lse_s + R;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
+    f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i)
+#pragma unroll
+      for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
+    float* csum = p.csum_part ? p.csum_part + ((long)b * NW + wave) * ld + h * DH : nullptr;
+    for (int half = 0; half < nhalves; ++half, ++u) {
+      char* cur = QD + (u & 1) * (2 * HALFB);
+      char* nxt = QD + ((u + 1) & 1) * (2 * HALFB);
+      const bool last_half = half + 1 == nhalves;
+      if (!last_half) issue_half(nxt, bh, half + 1);
+      else if (bh_next < BH) issue_half(nxt, bh_next, 0);
+      const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
+      // ------------------------------------------------------------------ phase A
+      if (k00 < R && !(p.dbg & 2)) {
+        const float kinf[RQ] = {(k00 + l15 < T) ? 0.f : INFINITY, (k00 + 16 + l15 < T) ? 0.f : INFINITY};
+        for (int pp = pp0; pp < pp1; ++pp) {
+          const int qb0 = pp * 32, ql = (pp - pp0) * 32;  // global / buffer-local first query row of the pair
+          const char* Qt = cur + (ql >> 6) * TILE;
+          const char* Ot = cur + HALFB + (ql >> 6) * TILE;
+          const int u32 = ql & 32;
+          u32x2 pdh[RQ][2], dsh[RQ][2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int q0 = qb0 + jj * 16;
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
+            if (q0 < R) {
+              f32x4 s_[RQ], dp[RQ];
+#pragma unroll
+              for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
+#pragma unroll
+              for (int s = 0; s < DH / 32; ++s) {
+                const bf16x8 qfr = frag_rows<DH>(Qt, u32 + jj * 16, s, l15, lg);
+                const bf16x8 ofr = frag_rows<DH>(Ot, u32 + jj * 16, s, l15, lg);
+#pragma unroll
+                for (int rq = 0; rq < RQ; ++rq) {
+                  s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
+                  dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
+                }
+              }
+              const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
+              const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
+#pragma unroll
+              for (int rq = 0; rq < RQ; ++rq) {
+                const unsigned key = k00 + rq * 16 + l15;
+                float pdv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
+                  const float pr = fast_exp2(s_[rq][r] * c - (l4[r] + kinf[rq]));
+                  float mk = 1.f;
+                  if (p.drop.thr) {
+                    const unsigned idx32 = (unsigned)(q0 + lg * 4 + r) * half_cols + (key >> 1);
+                    const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
+                    const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+                    mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
+                  }
+                  pdv[r] = pr * mk;
+                  dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+                }
+                pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
+                dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+                if (k00 + rq * 16 < R)
+                  *(u32x2*)(dSimg + (k00 + rq * 16 + l15) * DSP + (ql + jj * 16 + lg * 4) * 2) = dsh[rq][jj];
+              }
+            }
+          }
+          bf16x8 pf[RQ], df[RQ];
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) {
+            pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
+            df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
+          }
+#pragma unroll
+          for (int dt = 0; dt < DH / 16; ++dt) {
+            const bf16x8 otf = frag_cols<DH>(Ot, u32, u32 + 16, dt * 16, l15, lg);
+            const bf16x8 qtf = frag_cols<DH>(Qt, u32, u32 + 16, dt * 16, l15, lg);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
+              dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next unit's Q / dO (and a K image issued a unit ago) landed
+      __syncthreads();
+      if (last_half && bh_next < BH) issue_regs(bh_next);  // K / V rows are dead until the next head's phase A
+      // the next head's statistics, this half's share of the rows: loads now, arithmetic after phase B, into the other set
+      const int drow_lo = half * 128, drow_hi = min(R, drow_lo + 128);
+      if (bh_next < BH) delta_issue(bh_next, drow_lo, drow_hi);
+      // ------------------------------------------------------------------ phase B: dQ of query tile (2 pp0 + wave)
+      const int qt = pp0 * 2 + wave;
+      {
+        f32x4 dqt[DH / 16];
+#pragma unroll
+        for (int i = 0; i < DH / 16; ++i) dqt[i] = zero4();
+        const bool have = qt < nq && qt < pp1 * 2 && !(p.dbg & 1);
+        if (have) {
+          const int tq = l15 >> 2, tp = l15 & 3;
+          const char* dcol = dSimg + (wave * 16 + 4 * tp) * 2;
+          for (int ks = 0; ks < nks; ++ks) {
+            const int kb = ks * 32;
+            const bool hi_ok = kb + 16 < R;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 4 * lg + tq) * DSP));
+            bf16x4 hi = {0, 0, 0, 0};
+            if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16 + 4 * lg + tq) * DSP));
+            const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const char* Kt = Kimg + (kb >> 6) * TILE;
+            const int r0 = kb & 63;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) {
+              const bf16x8 ktf = frag_cols<DH>(Kt, r0, hi_ok ? r0 + 16 : r0, dt * 16, l15, lg);
+              dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[dt], 0, 0, 0);
+            }
+          }
+        }
+        const int q = qt * 16 + l15;
+        short* o = p.dqkv + ((long)b * T + q) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) {
+          const f32x4 v = dqt[dt] * p.scale;
+          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+          if (have && q < T) *(u32x2*)(o + dt * 16 + lg * 4) = pk;
+          else pk = (u32x2){0u, 0u};
+          if (csum) {  // this wave's dQ column sums: first half writes its partial row, the second adds to it
+            f32x4 t = rows16_sum(bf_round4(pk));
+            float* dst = csum + dt * 16 + lg * 4;
+            if (l15 == 0) {
+              if (half) t += *(const f32x4*)dst;
+              *(f32x4*)dst = t;
+            }
+          }
+        }
+      }
+      if (last_half) {  // dK, dV of this wave's keys and the column sums of everything this wave stored for the head
+        f32x4 csk[DH / 16], csv[DH / 16];
+#pragma unroll
+        for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          const int key = k00 + rq * 16 + l15;
+          if (key < T && !(p.dbg & 8)) {
+            short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * DH + h * DH;
+            short* ov = ok + p.H * DH;
+#pragma unroll
+            for (int dt = 0; dt < DH / 16; ++dt) {
+              const int d = dt * 16 + lg * 4;
+              const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
+              u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+              u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+              *(u32x2*)(ok + d) = pk;
+              *(u32x2*)(ov + d) = pv;
+              csk[dt] += bf_round4(pk);
+              csv[dt] += bf_round4(pv);
+            }
+          }
+        }
+        if (csum) {
+#pragma unroll
+          for (int dt = 0; dt < DH / 16; ++dt) {
+            const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
+            const int d = dt * 16 + lg * 4;
+            if (l15 == 0) {
+              *(f32x4*)(csum + HD + d) = tk;
+              *(f32x4*)(csum + 2 * HD + d) = tv;
+            }
+          }
+        }
+      }
+      if (bh_next < BH) delta_finish(bh_next, stats + ((hidx + 1) & 1) * (2 * R), drow_lo, drow_hi);
+      __syncthreads();  // dS and (after the last half) the K image are free; the next head's statistics are visible
+      if (last_half && bh_next < BH) issue_k(bh_next);  // lands during the next head's first phase A
+    }
+  }
+}
+
+static bool persist_fits(int T, int dh) {
+  const size_t rows = (T + 15) & ~15;
+  return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 16) <= 160 * 1024;
+}
+
 int g_attn_debug = 0;
-int g_attn_bwd_fused = 1;  // vit_set_option("attn_bwd_fused"): 0 = always the two-kernel backward
+int g_attn_bwd_fused = 3;  // vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent pipelined form where it fits (dh 64, T <= 224), else 1
 
 static bool fused_fits(int T, int dh) {
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
@@ -1608,6 +1917,17 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
     const size_t rows = (T + 15) & ~15;
     const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 8);
+    if (g_attn_bwd_fused == 3 && persist_fits(T, dh)) {
+      static bool attr = false;
+      if (!attr) {
+        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+      }
+      const size_t sm = 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 16);
+      hipLaunchKernelGGL(attn_bwd_persist_kernel, dim3(std::min(B * H, 256)), dim3(512), sm, st, a);
+      VIT_LAUNCH_CHECK();
+      return VIT_OK;
+    }
     const int nw = g_attn_bwd_fused == 2 ? 16 : 8;
 #define LAUNCH_FUSED(DH_, NW_)                                                                                           \
   do {                                                                                                                   \
