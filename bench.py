@@ -79,6 +79,42 @@ def launch_check(n_expected: int):
         raise SystemExit(f"--gpus {n_expected} but WORLD_SIZE={world}")
 
 
+def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, dt):
+    """N > 1: the same steps with the exchange switched off, and the bare all-reduce of the step's buckets."""
+    import torch
+
+    dist = torch.distributed
+    n_probe = min(args.steps, 10)
+    trainer.reducer, eng.grad_ready_cb = None, None
+    if hasattr(trainer.optimizer, "attach_reducer"):
+        trainer.optimizer.attach_reducer(None)
+    barrier()
+    t2 = time.perf_counter()
+    for i in range(n_probe):
+        trainer.training_step(module, batch, i)
+    barrier()
+    dt_off = time.perf_counter() - t2
+    trainer.reducer, eng.grad_ready_cb = red, red.bucket_ready
+    if hasattr(trainer.optimizer, "attach_reducer"):
+        trainer.optimizer.attach_reducer(red)
+    barrier()
+    t3 = time.perf_counter()
+    for _ in range(n_probe):
+        for lo, hi in eng.layout.buckets():
+            red.bucket_ready(lo, hi)
+        red.finish()
+    barrier()
+    dt_ar = time.perf_counter() - t3
+    t = torch.tensor([dt_off, dt_ar], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_off, dt_ar = float(t[0]), float(t[1])
+    alg = red.bytes_per_step / (dt_ar / n_probe) / 1e9
+    return {"ms_per_step_exchange_off": round(dt_off / n_probe * 1e3, 3),
+            "exposed_exchange_ms": round(ms_per_step_of(dt, args.steps) - dt_off / n_probe * 1e3, 3),
+            "bare_allreduce_ms": round(dt_ar / n_probe * 1e3, 3), "algbw_GBps": round(alg, 1),
+            "busbw_GBps": round(alg * 2 * (world - 1) / world, 1), "probe_steps": n_probe}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,33 +269,10 @@ def main():
         comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "exchange": red.mode,
                 "collectives_per_step": red.calls_per_step, "bytes_per_step": red.bytes_per_step}
         if not args.no_comm_probe:
-            n_probe = min(args.steps, 10)
-            trainer.reducer, eng.grad_ready_cb = None, None
-            barrier()
-            t2 = time.perf_counter()
-            for i in range(n_probe):
-                trainer.training_step(module, batch, i)
-            barrier()
-            dt_off = time.perf_counter() - t2
-            trainer.reducer, eng.grad_ready_cb = red, red.bucket_ready
-            barrier()
-            t3 = time.perf_counter()
-            for _ in range(n_probe):
-                for lo, hi in eng.layout.buckets():
-                    red.bucket_ready(lo, hi)
-                red.finish()
-            barrier()
-            dt_ar = time.perf_counter() - t3
-            t = torch.tensor([dt_off, dt_ar], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_off, dt_ar = float(t[0]), float(t[1])
-            alg = red.bytes_per_step / (dt_ar / n_probe) / 1e9
-            comm.update({"ms_per_step_exchange_off": round(dt_off / n_probe * 1e3, 3),
-                         "exposed_exchange_ms": round(ms_per_step_of(dt, args.steps) - dt_off / n_probe * 1e3, 3),
-                         "bare_allreduce_ms": round(dt_ar / n_probe * 1e3, 3), "algbw_GBps": round(alg, 1),
-                         "busbw_GBps": round(alg * 2 * (world - 1) / world, 1), "probe_steps": n_probe})
-    if rank == 0:
-        log(f"{args.steps} steps in {dt:.3f} s -> {world * B * args.steps / dt:.1f} images/s, loss {final_loss:.5f}")
+            try:
+                comm.update(comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, dt))
+            except Exception as e:  # noqa: BLE001 - the probe is extra evidence; `value` above is already measured
+                comm["probe_error"] = f"{type(e).__name__}: {e}"
 
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt

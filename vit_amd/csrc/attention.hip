@@ -974,6 +974,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
 // Two halves of 128 queries keep the dS image at 60 KiB: LDS = 3 x 26 KiB (Q, dO, K) + 58.5 KiB + statistics = 138 KiB at
 // T = 197, one workgroup per CU.  delta = rowsum(dO o (O + O_lo)) is computed up front from global O (loads issued before
 // the staging barrier) and dO from the LDS.
+// Dropout multipliers of 4 consecutive query rows (row0 .. row0+3) at ONE key for the key-owner orientation of the backward
+// kernels.  The mask is defined per (row, key pair): lanes l15 and l15 ^ 1 hold the two keys of a pair and would evaluate
+// the same four hashes; instead the even lane hashes rows 0, 1, the odd lane rows 2, 3, and they trade results across the
+// lane pair (a DPP move each): 2 hashes + 2 moves per 4 elements instead of 4 hashes.
+__device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, unsigned long long base, unsigned half_cols,
+                                                    unsigned row0, unsigned key, int l15, float (&mk)[4]) {
+  const unsigned odd = (unsigned)l15 & 1u;
+  const unsigned ra = row0 + 2u * odd;
+  const unsigned ha = drop_hash(d.k0, d.k1, base + (ra * half_cols + (key >> 1)));
+  const unsigned hb = drop_hash(d.k0, d.k1, base + ((ra + 1u) * half_cols + (key >> 1)));
+  const unsigned oa = (unsigned)__shfl_xor((int)ha, 1, 64), ob = (unsigned)__shfl_xor((int)hb, 1, 64);
+  const unsigned h[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned r16 = odd ? (h[r] >> 16) : (h[r] & 0xFFFFu);  // key parity == lane parity (key tiles start at even keys)
+    mk[r] = r16 >= d.thr ? d.scale : 0.f;
+  }
+}
+
 constexpr int DSP = 288;  // bytes per key row of the dS image: 128 queries x 2 B + 32 (4 consecutive rows hit disjoint banks)
 
 template <int DH>
@@ -1129,19 +1148,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) {
               const unsigned key = k00 + rq * 16 + l15;
-              float pdv[4], dsv[4];
+              float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+              if (p.drop.thr) drop_mask4_keyowner(p.drop, drop_base, half_cols, (unsigned)(q0 + lg * 4), key, l15, mk);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
-                float mk = 1.f;
-                if (p.drop.thr) {
-                  const unsigned idx32 = (unsigned)(q0 + lg * 4 + r) * half_cols + (key >> 1);
-                  const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
-                  const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
-                  mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
-                }
-                pdv[r] = pr * mk;
-                dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+                pdv[r] = pr * mk[r];
+                dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
               }
               pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
               dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
@@ -1428,20 +1441,14 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 #pragma unroll
               for (int rq = 0; rq < RQ; ++rq) {
                 const unsigned key = k00 + rq * 16 + l15;
-                float pdv[4], dsv[4];
+                float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+                if (p.drop.thr) drop_mask4_keyowner(p.drop, drop_base, half_cols, (unsigned)(q0 + lg * 4), key, l15, mk);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
                   const float pr = fast_exp2(s_[rq][r] * c - (l4[r] + kinf[rq]));
-                  float mk = 1.f;
-                  if (p.drop.thr) {
-                    const unsigned idx32 = (unsigned)(q0 + lg * 4 + r) * half_cols + (key >> 1);
-                    const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
-                    const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
-                    mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
-                  }
-                  pdv[r] = pr * mk;
-                  dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+                  pdv[r] = pr * mk[r];
+                  dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
                 }
                 pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
                 dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
