@@ -410,3 +410,31 @@ def test_cli_run_save_then_test_only(dev, tmp_path):
     assert m1.keys() == m2.keys() and "test_mae" in m1
     for k in m1:
         assert abs(float(m1[k]) - float(m2[k])) <= 1e-4 * max(1.0, abs(float(m1[k]))), (k, m1[k], m2[k])
+
+
+def test_fused_adamw_refuses_replaced_grad_under_reducer(dev):
+    """under data parallelism the flat gradient buffer holds the rank-averaged gradient when step() runs; a
+    `.grad` that is no longer the flat buffer's view (a hook / an accumulation replaced it) must not silently overwrite it."""
+    from vit_amd.optimizer import FusedAdamW
+
+    module, _ = make(c1_config())
+    model = module.model.to(dev)
+    model.set_precision("32")
+    model.eval()
+    b = next(iter(Batches(16, 3)))
+    opt = FusedAdamW(model, lr=1e-3)
+    model(b[0].cuda(), labels=b[2].cuda()).loss.backward()
+    name = "vit.encoder.layer.0.output.dense.weight"
+    p = dict(model.named_parameters())[name]
+    p.grad = p.grad.clone()  # what a gradient hook or `loss1.backward(); loss2.backward()` accumulation leaves behind
+
+    class Reducer:  # the one attribute FusedAdamW looks at
+        mode = "allreduce"
+
+    opt.attach_reducer(Reducer())
+    with pytest.raises(RuntimeError, match="flat gradient buffer"):
+        opt.step()
+    opt.attach_reducer(None)  # single process: the replaced gradient is folded back and the step proceeds
+    before = p.detach().clone()
+    opt.step()
+    assert not torch.equal(before, p)

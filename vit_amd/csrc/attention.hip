@@ -573,12 +573,14 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq) a[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][s], a[rq], 0, 0, 0);
         }
+        // raw scores: the scale rides in the exp2's FMA below (max(c s) = c max(s), c > 0); only a tile that straddles T
+        // needs the per-key validity select
+        const bool edge = kb + j * 16 + 16 > T;
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kb + j * 16 + lg * 4 + r;
-            a[rq][r] = key < T ? a[rq][r] * c : -INFINITY;
+            if (edge && kb + j * 16 + lg * 4 + r >= T) a[rq][r] = -INFINITY;
             mx[rq] = fmaxf(mx[rq], a[rq][r]);
           }
           st[rq][j] = a[rq];
@@ -590,15 +592,16 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
     }
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) {
-      const float mn = fmaxf(m[rq], grp4_max(mx[rq]));
-      const float alpha = fast_exp2(m[rq] - mn);
+      const float mn = fmaxf(m[rq], grp4_max(mx[rq]));  // running max of the RAW scores
+      const float alpha = fast_exp2((m[rq] - mn) * c);
       m[rq] = mn;
+      const float mnc = mn * c;
       float ls = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[rq][j][r] = fast_exp2(st[rq][j][r] - mn);
+          st[rq][j][r] = fast_exp2(fmaf(st[rq][j][r], c, -mnc));
           ls += st[rq][j][r];
         }
       l[rq] = l[rq] * alpha + ls;
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
           if (p.ctx_lo) store_lo(p.ctx_lo + (o - p.ctx) + d, v, pk);
         }
       }
-      if (lg == 0) p.lse[(long)bh * T + q] = (m[rq] + log2f(lt)) * LN2;
+      if (lg == 0) p.lse[(long)bh * T + q] = (m[rq] * c + log2f(lt)) * LN2;
     }
   }
 }
