@@ -572,3 +572,29 @@ def test_conv1d_tokenizer_matches_reference(dev, tag, precision):
         worst = max(worst, e)
         assert e < gtol, (name, e)
     print(f"[conv/{tag} {precision}] tokens {e_tok:.2e}, hidden states {e_hs:.2e}, logits {e_log:.2e}, worst grad {worst:.2e}")
+
+
+def test_attention_forward_hooks_receive_maps(dev):
+    """The reference's viz callback registers forward hooks on `...encoder.layer.N.attention.attention` and reads output[1]
+    as the attention map (src/viz/viz_callback.py:183-214, 231-235).  MyViT has those module names; a registered hook is
+    called with (context, probabilities) of that layer, equal to what output_attentions=True returns."""
+    rc, g, sd, model, x, labels = setup("c1", dev, precision="32")
+    model.eval()
+    seen = {}
+    names = [n for n, _ in model.named_modules() if "encoder.layer" in n and n.endswith(".attention.attention")]
+    assert names == [f"vit.encoder.layer.{i}.attention.attention" for i in range(3)]
+    mods = dict(model.named_modules())
+    handles = [mods[n].register_forward_hook(lambda m, inp, out, n=n: seen.__setitem__(n, out)) for n in names[:2]]
+    out = model(x, labels=labels)
+    assert out.attentions is None and sorted(seen) == names[:2]
+    ref = model(x, labels=labels, output_attentions=True)
+    for i, n in enumerate(names[:2]):
+        ctx, probs = seen[n]
+        assert probs.shape == (x.shape[0], 2, 129, 129) and ctx.shape == (x.shape[0], 129, 32)
+        assert torch.equal(probs, ref.attentions[i])
+        assert rel(probs, torch.from_numpy(g["attn0"])) < 1e-4 if i == 0 else True
+    for h in handles:
+        h.remove()
+    seen.clear()
+    model(x, labels=labels)
+    assert not seen

@@ -313,7 +313,7 @@ class ViTEngine:
         return 1 + 4 * layer + which
 
     def forward(self, x: torch.Tensor, labels: Optional[torch.Tensor], training: bool, need_grad: bool,
-                output_hidden_states: bool = False, output_attentions: bool = False):
+                output_hidden_states: bool = False, output_attentions: bool = False, capture_ctx: Optional[list] = None):
         c = self.cfg
         self._ensure_device_state()
         if x.dim() != 2 or x.shape[1] != c.image_size:
@@ -368,6 +368,8 @@ class ViTEngine:
                              lse=a["lse"][j], ctx_lo=a["ctx_lo"][j])
             if output_attentions:
                 atts.append(vf.attention_probs(a["qkv"][j], B, H, T, dh, scale))
+            if capture_ctx is not None:  # per-layer context for forward hooks on the attention modules
+                capture_ctx.append(a["ctx"][j].view(B, T, D).clone())
             vf.gemm(a["ctx"][j], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, out=y,
                     bias=self.p(pre + "attention.output.dense.bias"), dropout=(ph, seed, self._site(i, 1)))
             self._ln_res(xin, y, a["x1"][j], pre + "layernorm_after", a["h2"][j], a["mean2"][j], a["rstd2"][j])
