@@ -514,6 +514,22 @@ __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, lon
   }
 }
 
+// LDS-DMA staging of a [rows x 128 B] tile image (head_dim 64): 1 KiB of consecutive LDS per wave-instruction, the XOR
+// swizzle applied to the GLOBAL address of each lane; rows past T are clamped to row T - 1 (a DMA has no bounds check).
+#define GLB_AS __attribute__((address_space(1)))
+
+__device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, int row0, int nrows_img, int T, int wave,
+                                           int lane, int nwaves = 8) {
+  // image = nrows_img rows of 128 B, tile layout (row r at r * 128, chunk c at ((c ^ swz(r)) << 4))
+  const int p = lane & 7;
+  for (int j = wave; j < (nrows_img >> 3); j += nwaves) {
+    const int r = (j << 3) + (lane >> 3);
+    const int c = p ^ swz<64>(r & 63);
+    const int grow = min(row0 + r, T - 1);
+    __builtin_amdgcn_global_load_lds((GLB_AS void*)(g + (long)grow * ld + c * 8), (LDS_AS void*)(img + j * 1024), 16, 0, 0);
+  }
+}
+
 template <int DH, int RQ>
 __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
@@ -534,7 +550,17 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
   const int rows_alloc = (T + 15) & ~15;
   char* Vimg = smem + rows_alloc * (DH * 2);
-  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
+  if (DH == 64 && dh == 64) {
+    // no registers, no zero-fill moves, no address arithmetic per chunk: this kernel saturates the VALU (PMC: 3 waves x 33 %
+    // VALU-active per SIMD) and the register-staged form spent ~300 VALU instructions per wave here.  Keys past T are
+    // masked to -inf in the edge tile, so the clamped duplicate rows are never used.
+    const int nwv = blockDim.x >> 6;
+    dma_rows64(Kimg, kb_, ld, 0, rows_alloc, T, wave, lane, nwv);
+    dma_rows64(Vimg, vb, ld, 0, rows_alloc, T, wave, lane, nwv);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
+  }
   __syncthreads();
   const int q00 = (part * p.wpw + wave) * RQ * 16;
   if (q00 >= T) return;  // no barrier after this point
@@ -1285,20 +1311,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
 // Rows past T are clamped to row T - 1 instead of zero-filled (a DMA has no bounds check): their probabilities are 0 through
 // lse = +inf (queries) or a -inf added to the exponent (keys), so nothing depends on what the duplicate rows hold.
 // dh == 64 only (ViT-B / ViT-L); T <= 224 (LDS: 64 KiB of Q / dO buffers + K + a 128-query dS image + statistics).
-#define GLB_AS __attribute__((address_space(1)))
-
-__device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, int row0, int nrows_img, int T, int wave,
-                                           int lane) {
-  // image = nrows_img rows of 128 B, tile layout (row r at r * 128, chunk c at ((c ^ swz(r)) << 4))
-  const int p = lane & 7;
-  for (int j = wave; j < (nrows_img >> 3); j += 8) {
-    const int r = (j << 3) + (lane >> 3);
-    const int c = p ^ swz<64>(r & 63);
-    const int grow = min(row0 + r, T - 1);
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(g + (long)grow * ld + c * 8), (LDS_AS void*)(img + j * 1024), 16, 0, 0);
-  }
-}
-
 __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
   resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
