@@ -14,7 +14,7 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
+extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2, g_krot;  // gemm2.hip
 extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_debug;  // attention.hip
 
 static thread_local char g_err[512] = "";
@@ -97,6 +97,10 @@ int vit_set_option(const char* name, int value) {
   }
   if (strcmp(name, "gemm_half_tail") == 0) {
     vit::g_half_tail = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "gemm_krot") == 0) {
+    vit::g_krot = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_ngroups") == 0) {

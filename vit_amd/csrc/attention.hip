@@ -471,11 +471,36 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict
 // LDS store, so a workgroup pays ONE memory latency for its whole working set (a load->store loop paid ten).
 // column sums of a wave's 16-row x 4-column register tile over its rows (lanes that share lane >> 4), bf16-rounded like
 // the stored values; the four lanes with l15 == 0 hold the result
-__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+  // v + (v moved within its 16-lane row): DPP moves are plain VALU ops; __shfl_xor goes through ds_bpermute (LDS crossbar)
+  int m;
+  const int iv = __builtin_bit_cast(int, v);
+  switch (ctrl_sel) {
+    case 0: m = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, false); break;   // row_ror:8
+    case 1: m = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xF, 0xF, false); break;   // row_ror:4
+    case 2: m = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    default: m = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+  }
+  return v + __builtin_bit_cast(float, m);
+}
+// sum over groups of CPR (4 or 8) consecutive lanes, result in every lane of the group: quad swaps, then (8) the mirror of the
+// 8-lane half row brings the other quad's sum
+template <int CPR>
+__device__ __forceinline__ float sum_lanes_cpr(float x) {
+  x = dpp_add(x, 3);
+  x = dpp_add(x, 2);
+  if (CPR == 8) {
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x += __builtin_bit_cast(float, m);
+  }
+  return x;
+}
+__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {  // every lane ends with the sum over its 16-lane row
 #pragma unroll
-  for (int m = 1; m < 16; m <<= 1) {
-    v[0] += __shfl_xor(v[0], m, 64); v[1] += __shfl_xor(v[1], m, 64);
-    v[2] += __shfl_xor(v[2], m, 64); v[3] += __shfl_xor(v[3], m, 64);
+  for (int c = 0; c < 4; ++c) {
+    float x = v[c];
+    x = dpp_add(x, 0); x = dpp_add(x, 1); x = dpp_add(x, 2); x = dpp_add(x, 3);
+    v[c] = x;
   }
   return v;
 }
@@ -1013,7 +1038,9 @@ __device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, unsigned l
   const unsigned ra = row0 + 2u * odd;
   const unsigned ha = drop_hash(d.k0, d.k1, base + (ra * half_cols + (key >> 1)));
   const unsigned hb = drop_hash(d.k0, d.k1, base + ((ra + 1u) * half_cols + (key >> 1)));
-  const unsigned oa = (unsigned)__shfl_xor((int)ha, 1, 64), ob = (unsigned)__shfl_xor((int)hb, 1, 64);
+  // lane ^ 1 by DPP quad_perm [1,0,3,2] (one VALU move; __shfl_xor would go through ds_bpermute)
+  const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
+  const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
   const unsigned h[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1118,8 +1145,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
       float d_ = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(dv[e]);
-#pragma unroll
-      for (int m = 1; m < CPR; m <<= 1) d_ += __shfl_xor(d_, m, 64);
+      d_ = sum_lanes_cpr<CPR>(d_);
       if (dch == 0) {
         del_s[row] = row < T ? d_ : 0.f;
         lse_s[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
@@ -1380,8 +1406,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
       float d_ = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(d8[e]);
-#pragma unroll
-      for (int m = 1; m < CPR; m <<= 1) d_ += __shfl_xor(d_, m, 64);
+      d_ = sum_lanes_cpr<CPR>(d_);
       if (dch == 0 && row < row_hi && row < R) {
         st[R + row] = row < T ? d_ : 0.f;
         st[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;  // (prefetching it with the chunks cost 4 spills: slower)

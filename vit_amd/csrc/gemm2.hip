@@ -50,6 +50,7 @@ struct Gemm2Args {
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
   int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
   int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
+  int krot;  // ping-pong kernel: K-walk rotation step per tile (0 = every tile starts at K-tile 0); see cursor_next
   int grp2;  // ping-pong kernel: XCDs 0-3 walk the lower half of the N-tiles, XCDs 4-7 the upper half (see tile_coords)
 };
 
@@ -598,14 +599,31 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
     bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
   };
+  // K rotation (p.krot): the workgroups that share an operand panel (same tm: the A panel; same tn: the B panel) run in
+  // lock step, so every line of the panel is requested by all of them within one miss latency and the requests that find
+  // the line pending go to the fabric again (PMC: FC1 reads 376 MB against an 82 MB operand set at a 68 % L2 hit rate).
+  // Starting each tile's K walk at a different K-tile, (tm + tn) * krot mod nk, spreads the sharers over the panel: one
+  // of them misses a line, the others find it cached later.  The sum order of a tile changes with its coordinates -- still a
+  // fixed function of the problem, so results stay run-to-run deterministic.
+  auto rot_of = [&](int tm, int tn) -> int {
+    if (!p.krot) return 0;
+    const int r = ((tm + tn) * p.krot) % nk;
+    return r;
+  };
   // walking cursor over this workgroup's flat (output tile, K-tile) sequence: no division in the loop
-  int cj = 0, ckt = 0, ctm, ctn;
+  int cj = 0, ckt = 0, ctm, ctn, crot;
   tile_coords(0, ctm, ctn);
+  crot = rot_of(ctm, ctn);
   auto cursor_next = [&](const char*& ab, const char*& bb) {  // bases of the cursor's K-tile, then advance
-    base_of(ctm, ctn, ckt, ab, bb);
+    int kk = ckt + crot;
+    if (kk >= nk) kk -= nk;
+    base_of(ctm, ctn, kk, ab, bb);
     if (++ckt == nk) {
       ckt = 0;
-      if (++cj < my_tiles) tile_coords(cj, ctm, ctn);
+      if (++cj < my_tiles) {
+        tile_coords(cj, ctm, ctn);
+        crot = rot_of(ctm, ctn);
+      }
     }
   };
   // one half-tile = 2 LDS-DMA instructions per thread; destination: slot + round*8 KiB + wave*1 KiB (+ lane*16)
@@ -940,6 +958,7 @@ static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
   return launch_half<0, 1, 6>(a, st);
 }
 
+int g_krot = 0;  // vit_set_option("gemm_krot"): 0 = off, 1 = automatic K-walk rotation step, >1 = that step
 int g_grp2 = 1;  // vit_set_option("gemm_ngroups"): 1 = two N-groups for weights larger than an L2 (see tile_coords)
 int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
@@ -1087,6 +1106,14 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     // just enough workgroups for that many rounds: the idle CUs' power budget goes to the busy ones' clock
     a.nblk = cdiv(ntile - half_tail, cdiv(ntile - half_tail, slots));
     grid = dim3(a.nblk, splits);
+  }
+  a.krot = 0;
+  if (cfg == 5 && g_krot) {
+    const int nk_ = (splits > 1 ? a.k_per_split : d->K) / 64;
+    // sharers of a panel: tiles_n for A, tiles_m for B (per K-slice); spread them evenly over the K-tiles
+    const int sharers = std::max(1, std::min(std::max(a.tiles_m, a.tiles_n), nk_));
+    a.krot = g_krot > 0 ? std::max(1, nk_ / sharers) : 0;
+    if (g_krot > 1) a.krot = g_krot;
   }
   a.grp2 = 0;
   if (cfg == 5 && g_grp2 && splits == 1 && !half_tail && !a.lin_split && (a.tiles_n % 2) == 0 &&
