@@ -152,6 +152,7 @@ class ViTEngine:
         # weight-gradient GEMMs on a second HIP stream (see _dw): None = off
         self.side_stream: Optional[torch.cuda.Stream] = None
         self._side_handle = None
+        self._side_reads: Dict[str, object] = {}
         self.overlap_dw = True
         self._gen = 0  # bumped by every forward: the activation arena holds ONE forward, backward checks it is still that one
         self.grad_ready_cb: Optional[Callable[[int, int], None]] = None
@@ -289,7 +290,7 @@ class ViTEngine:
         self.tmp = {}
         if train:
             self.tmp = dict(
-                dxa=E((M, D), f32), dxb=E((M, D), f32), dy=G(D, b16), dU=G(Fd, b16), dh=G(D, b16),
+                dxa=E((M, D), f32), dxb=E((M, D), f32), dy=G(D, b16), dy2=G(D, b16), dU=G(Fd, b16), dh=G(D, b16),
                 dqkv=G(3 * D, b16), dctx=G(D, b16), delta=E((B * H, T), f32), dpatch=E((B * N, D), b16),
                 dlast=E((B, T, D), f32),
             )
@@ -413,23 +414,41 @@ class ViTEngine:
                                   self.cfg.layer_norm_eps, out=out, mean=mean, rstd=rstd)
 
     # ------------------------------------------------------------------ weight gradients beside the data path
-    def _dw(self, *args, **kw):
+    def _dw(self, *args, reads=(), **kw):
         """A weight-gradient GEMM (dW = dY^T X, deterministic split-K).  Its only consumer is the optimizer at the end of the
         step, so it is enqueued on a second HIP stream (own vit_handle = own split-K workspace) right after its operands are
-        complete, and runs beside the dX GEMM / attention kernels that continue the chain on the main stream: the 256-CU
-        rounds of one kernel leave holes (N = 768 GEMMs: 2.31 rounds; every kernel's ramp and drain) that the other
-        stream's workgroups fill.  `_join_side()` brings the streams together before anything overwrites an operand a
-        pending dW still reads (the next LayerNorm backward rewrites dy) and before the gradients are consumed."""
+        complete and runs beside whatever continues the chain on the main stream.  What that buys: a GEMM workgroup (128 KiB
+        of LDS, 8 waves) and the LayerNorm-backward blocks (hardly any LDS) fit one CU together -- the latency-bound dW kernel
+        (PMC: 52 % of its wave-cycles parked) and the HBM-bound LayerNorm pass complement each other; beside another GEMM or
+        the attention backward (152 KiB of LDS) it only fills the holes of partial rounds.
+        `reads` names the scratch buffers the GEMM reads; `_before_write(name)` makes the main stream wait for the last such
+        reader before a kernel overwrites the buffer (one layer later, so the wait is normally already satisfied)."""
         if self.side_stream is None:
             return vf.gemm(*args, **kw)
         main = torch.cuda.current_stream(self.flat.device)
         self.side_stream.wait_stream(main)
         with torch.cuda.stream(self.side_stream), vf.use_handle(self._side_handle):
-            return vf.gemm(*args, **kw)
+            out = vf.gemm(*args, **kw)
+            if reads:
+                ev = torch.cuda.Event()
+                ev.record(self.side_stream)
+                for name in reads:
+                    self._side_reads[name] = ev
+        return out
+
+    def _before_write(self, *names):
+        if self.side_stream is None:
+            return
+        main = torch.cuda.current_stream(self.flat.device)
+        for name in names:
+            ev = self._side_reads.pop(name, None)
+            if ev is not None:
+                main.wait_event(ev)
 
     def _join_side(self):
         if self.side_stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.side_stream)
+            self._side_reads.clear()
 
     def _setup_side(self):
         from . import _cabi
@@ -489,22 +508,25 @@ class ViTEngine:
             pre = f"vit.encoder.layer.{i}."
             # x2 = dropout(g W2^T + b2) + x1      (t["dy"] = mask * dx and db2 were produced by the LN backward above)
             self._dw(t["dy"], a["g"][i], M=D, N=Fd, K=Mp, a_trans=True, b_trans=True, out=self.g(pre + "output.dense.weight"),
-                     split_k=-1)
+                     split_k=-1, reads=("dy",))
+            self._before_write("dU")
             vf.gemm(t["dy"], self.w16(pre + "output.dense.weight"), M=Mp, N=Fd, K=D, b_trans=True, out=t["dU"],
                     act=vf.ACT_MUL_AUX, aux_in=a["u"][i], colsum_out=self.g(pre + "intermediate.dense.bias"))
             self._dw(t["dU"], a["h2"][i], M=Fd, N=D, K=Mp, a_trans=True, b_trans=True,
-                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1)
+                     out=self.g(pre + "intermediate.dense.weight"), split_k=-1, reads=("dU",))
             vf.gemm(t["dU"], self.w16(pre + "intermediate.dense.weight"), M=Mp, N=D, K=Fd, b_trans=True, out=t["dh"])
             # x1 = dropout(ctx Wo^T + bo) + x:  LN2 backward -> dx1, and dya = mask * dx1 with dbo
-            self._join_side()  # the pending dW GEMMs read t["dy"], which this pass rewrites
+            # this pass writes the OTHER dy buffer: the FC2 weight gradient still reading t["dy"] keeps running beside it
+            self._before_write("dy2")
             vf.layernorm_bwd_fused(t["dh"], a["x1"][i], self.p(pre + "layernorm_after.weight"), a["mean2"][i],
                                    a["rstd2"][i], dx, dx_other, self.g(pre + "layernorm_after.weight"),
-                                   self.g(pre + "layernorm_after.bias"), t["dy"],
+                                   self.g(pre + "layernorm_after.bias"), t["dy2"],
                                    self.g(pre + "attention.output.dense.bias"), (ph, seed, self._site(i, 1)))
             dx, dx_other = dx_other, dx
-            self._dw(t["dy"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
-                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1)
-            vf.gemm(t["dy"], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, b_trans=True, out=t["dctx"])
+            self._dw(t["dy2"], a["ctx"][i], M=D, N=D, K=Mp, a_trans=True, b_trans=True,
+                     out=self.g(pre + "attention.output.dense.weight"), split_k=-1, reads=("dy2",))
+            vf.gemm(t["dy2"], self.w16(pre + "attention.output.dense.weight"), M=Mp, N=D, K=D, b_trans=True, out=t["dctx"])
+            self._before_write("dqkv")
             # the QKV bias gradient = column sums of dqkv: taken by the attention kernels on their way out, unless RoPE
             # sits in between (then after the inverse rotation, by the column-sum kernel)
             vf.attention_bwd(a["qkv"][i], a["ctx"][i], t["dctx"], a["lse"][i], B, H, T, dh, scale,
@@ -514,9 +536,11 @@ class ViTEngine:
                 vf.rope_qk(t["dqkv"], rope[0], rope[1], T, H, dh, inverse=True)
                 vf.colsum(t["dqkv"], out=self._qkv_bias(i, self.grads))
             self._dw(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
-                     split_k=-1)
+                     split_k=-1, reads=("dqkv",))
             vf.gemm(t["dqkv"], self._qkv16(i), M=Mp, N=D, K=3 * D, b_trans=True, out=t["dh"])
-            self._join_side()  # dW(out-proj) read t["dy"], dW(qkv) reads t["dqkv"]; the gradients of this layer complete
+            if cb:
+                self._join_side()  # data parallel: the layer's bucket is handed to the exchange below, complete
+            self._before_write("dy")  # the LayerNorm backward below rewrites t["dy"] (read by this layer's FC2 weight gradient)
             if i > 0:
                 # LN1 backward -> dx (input of this layer = output of layer i-1), plus layer i-1's FC2 pieces
                 prev = f"vit.encoder.layer.{i - 1}."

@@ -67,6 +67,9 @@ class GraphedTrainStep:
         eng._ensure_device_state()
         keep = (eng.flat.clone(), optimizer._m.clone(), optimizer._v.clone(), int(optimizer._step), int(eng.step_counter))
         # warm-up on a side stream (torch's capture protocol): sizes the arena / workspace, sets the kernels' LDS attributes
+        # one stream inside the graph: two-branch graphs (the weight-gradient GEMMs on their second stream) replayed 0.7 ms per
+        # step SLOWER than the same two streams launched eagerly on this stack
+        eng.overlap_dw = False
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         _cabi.check(self.h.lib.vit_step_state_bind(self.h.h, self.state.data_ptr()), "vit_step_state_bind")
