@@ -123,3 +123,28 @@ def test_checkpointer_keeps_best_and_last(tmp_path):
     assert float(model_state_from_checkpoint(load_checkpoint_file(ck.resolve("last")))["w"]) == 4.0
     mx = Checkpointer(str(tmp_path / "m"), "val_acc", "max")
     assert mx.better(0.1) and not (mx.__setattr__("best_score", 0.5) or mx.better(0.4)) and mx.better(0.6)
+
+
+def test_metrics_against_scikit_learn():
+    """torchmetrics (what the reference uses, src/vit.py:3,66-73) is not in this image, so the metric classes cannot be
+    pinned on it; scikit-learn is an independent implementation of the same definitions (MAE, MSE, R^2, accuracy)."""
+    sk = pytest.importorskip("sklearn.metrics")
+    from vit_amd.metrics import Accuracy, MeanAbsoluteError, MeanSquaredError, R2Score
+
+    rng = np.random.default_rng(7)
+    t = rng.random(257).astype(np.float32)
+    p = (0.1 + 0.85 * t + 0.07 * rng.standard_normal(257)).astype(np.float32)
+    mae, mse, r2 = MeanAbsoluteError(), MeanSquaredError(), R2Score()
+    for a in range(0, 257, 50):  # ragged last batch
+        mae(torch.from_numpy(p[a:a + 50]), torch.from_numpy(t[a:a + 50]))
+        mse(torch.from_numpy(p[a:a + 50]), torch.from_numpy(t[a:a + 50]))
+        r2(torch.from_numpy(p[a:a + 50]), torch.from_numpy(t[a:a + 50]))
+    assert abs(float(mae.compute()) - sk.mean_absolute_error(t, p)) < 1e-6
+    assert abs(float(mse.compute()) - sk.mean_squared_error(t, p)) < 1e-6
+    assert abs(float(r2.compute()) - sk.r2_score(t, p)) < 1e-5
+    y = rng.integers(0, 5, 300)
+    logits = rng.standard_normal((300, 5)).astype(np.float32)
+    acc = Accuracy()
+    for a in range(0, 300, 64):
+        acc(torch.from_numpy(logits[a:a + 64]), torch.from_numpy(y[a:a + 64]))
+    assert abs(float(acc.compute()) - sk.accuracy_score(y, logits.argmax(1))) < 1e-7
