@@ -492,6 +492,55 @@ def make_conv():
     np.savez_compressed(path, **out)
     print(f"[conv] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
+def make_data():
+    """Dataset contract (src/dataloader/spec_datasets.py:37-110, src/dataloader/base.py:312-326): the
+    reference's own `RegSpecDataset` built through its `from_config`, handed in-memory tensors in place of the HDF5 read
+    (h5py is absent: `load_data`, which also clips the flux at zero and thresholds log_g for classification, cannot run, so
+    those two lines stay unpinned), then its own `_maybe_normalize_labels`, `_set_noise` and `__getitem__`: label
+    normalisation with the training split's statistics re-used on the validation split (what
+    `ViTDataModule.setup_test_dataset` copies, src/vit.py:43-52), fixed-seed validation noise, 3- / 4-tuple items."""
+    _import_reference()
+    from src.dataloader.spec_datasets import RegSpecDataset
+
+    rng = np.random.Generator(np.random.PCG64(99))
+    out = {}
+    n_tr, n_va, Lp = 12, 7, 40
+    flux_tr = np.abs(rng.standard_normal((n_tr, Lp))).astype(np.float32)
+    err_tr = (0.1 * np.abs(rng.standard_normal((n_tr, Lp)))).astype(np.float32)
+    flux_va = np.abs(rng.standard_normal((n_va, Lp))).astype(np.float32)
+    err_va = (0.1 * np.abs(rng.standard_normal((n_va, Lp)))).astype(np.float32)
+    out.update(flux_tr=flux_tr, err_tr=err_tr, flux_va=flux_va, err_va=err_va)
+    for tag, ncol in (("one", 1), ("three", 3)):
+        p_tr = (3.0 + 2.0 * rng.standard_normal((n_tr, ncol))).astype(np.float32)
+        p_va = (3.0 + 2.0 * rng.standard_normal((n_va, ncol))).astype(np.float32)
+        if ncol == 1:
+            p_tr, p_va = p_tr[:, 0], p_va[:, 0]
+        out[f"{tag}_p_tr"], out[f"{tag}_p_va"] = p_tr, p_va
+        for norm in ("minmax", "standard", "none"):
+            cfg = {"data": {"file_path": "unused", "param": "log_g" if ncol == 1 else "T_eff,log_g,M_H", "label_norm": norm},
+                   "noise": {"noise_level": 0.5}}
+            tr = RegSpecDataset.from_config(cfg)
+            tr.flux, tr.error = torch.from_numpy(flux_tr), torch.from_numpy(err_tr)
+            tr.labels = torch.tensor(p_tr).float()          # spec_datasets.py:60
+            tr._maybe_normalize_labels("fit")
+            va = RegSpecDataset.from_config(cfg)
+            va.flux, va.error = torch.from_numpy(flux_va), torch.from_numpy(err_va)
+            va.labels = torch.tensor(p_va).float()
+            for k in ("label_norm", "label_mean", "label_std", "label_min", "label_max"):  # vit.py:47-51
+                setattr(va, k, getattr(tr, k))
+            va._maybe_normalize_labels("val")
+            va._set_noise()                                   # base.py:312-326 (seed 42)
+            key = f"{tag}_{norm}"
+            out[f"{key}_labels_tr"], out[f"{key}_labels_va"] = tr.labels.numpy(), va.labels.numpy()
+            out[f"{key}_noisy_va"] = va.noisy.numpy()
+            item_tr, item_va = tr[3], va[2]
+            assert len(item_tr) == 3 and len(item_va) == 4
+            out[f"{key}_item_va_noisy"], out[f"{key}_item_va_label"] = item_va[0].numpy(), np.asarray(item_va[3].numpy())
+            out[f"{key}_item_tr_label"] = np.asarray(item_tr[2].numpy())
+    path = os.path.join(ROOT, "tests", "golden", "data.npz")
+    np.savez_compressed(path, **out)
+    print(f"[data] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
 
 def main():
     torch.manual_seed(0)
@@ -515,6 +564,7 @@ def main():
     make_rope()
     make_prep()
     make_conv()
+    make_data()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -525,7 +575,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

@@ -299,3 +299,29 @@ def test_oracle_conv_tokenizer_matches_reference(tag):
     for k, p in tr.params.items():
         if f"{tag}_grad/{k}" in g.files and float(np.linalg.norm(g[f"{tag}_grad/{k}"])) > 1e-6:
             assert rel(p.grad, g[f"{tag}_grad/{k}"]) < 5e-4, k
+
+
+@pytest.mark.parametrize("tag", ["one", "three"])
+@pytest.mark.parametrize("norm", ["minmax", "standard", "none"])
+def test_spec_dataset_matches_reference_dataset_classes(tag, norm):
+    """tests/golden/data.npz: outputs of the reference's own `RegSpecDataset` (built by its `from_config`, fed in-memory
+    tensors; `_maybe_normalize_labels`, `_set_noise`, `__getitem__`: src/dataloader/spec_datasets.py:37-110,
+    src/dataloader/base.py:312-326).  `SpecDataset` must reproduce them: label normalisation with the TRAINING split's
+    statistics on the validation split, the fixed-seed validation noise bit for bit, the 3- / 4-tuple items.
+    (The flux clip and the log_g > 2.5 class threshold sit in the HDF5-reading `load_data`, which cannot run here: unpinned.)"""
+    from vit_amd.data import SpecDataset
+
+    g = np.load(os.path.join(GOLD, "data.npz"))
+    key = f"{tag}_{norm}"
+    tr = SpecDataset(g["flux_tr"], g["err_tr"], g[f"{tag}_p_tr"], task="reg", stage="train", label_norm=norm, noise_level=0.5)
+    va = SpecDataset(g["flux_va"], g["err_va"], g[f"{tag}_p_va"], task="reg", stage="val", label_norm=norm, noise_level=0.5,
+                     stats=tr.stats)
+    assert torch.allclose(tr.labels, torch.from_numpy(g[f"{key}_labels_tr"]), rtol=0, atol=1e-6)
+    assert torch.allclose(va.labels, torch.from_numpy(g[f"{key}_labels_va"]), rtol=0, atol=1e-6)
+    assert torch.equal(va.noisy, torch.from_numpy(g[f"{key}_noisy_va"]))  # torch.manual_seed(42) stream, same draw order
+    item_tr, item_va = tr[3], va[2]
+    assert len(item_tr) == 3 and len(item_va) == 4
+    assert torch.equal(item_va[0], torch.from_numpy(g[f"{key}_item_va_noisy"]))
+    assert torch.allclose(item_va[3], torch.from_numpy(g[f"{key}_item_va_label"]), atol=1e-6)
+    assert torch.allclose(item_tr[2], torch.from_numpy(g[f"{key}_item_tr_label"]), atol=1e-6)
+    assert tr.noisy is None  # training: noise is drawn on the device per step (vit.py:86-88), not stored
