@@ -44,7 +44,8 @@ def _import_reference():
     if "lightning" not in sys.modules:
         L = stub("lightning", LightningModule=type("LightningModule", (object,), {}),
                  LightningDataModule=type("LightningDataModule", (object,), {}),
-                 Trainer=type("Trainer", (object,), {}), seed_everything=lambda *a, **k: None)
+                 Trainer=type("Trainer", (object,), {}), Callback=type("Callback", (object,), {}),
+                 seed_everything=lambda *a, **k: None)
         pt = stub("lightning.pytorch")
         cb = stub("lightning.pytorch.callbacks", Callback=type("Callback", (object,), {}))
         pt.callbacks = cb
@@ -541,6 +542,147 @@ def make_data():
     np.savez_compressed(path, **out)
     print(f"[data] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
+OPT_CASES = {
+    "baseline_plateau": {"type": "AdamW", "lr": 0.001, "lr_sch": "plateau", "factor": 0.8, "patience": 10, "monitor_metric": "mae"},
+    "plain_adam": {"lr": 3e-4},
+    "sgd_wd": {"type": "sgd", "lr": 0.01, "weight_decay": 0.1},
+    "cosine": {"type": "adamw", "lr": 1e-3, "lr_sch": "cosine", "ep": 40, "eta_min": 1e-5},
+    "cosine_warmup_epochs": {"lr": 1e-3, "lr_sch": "cosine", "ep": 40, "warmup": {"epochs": 2}},
+    "cosine_warmup_ratio": {"lr": 2e-3, "lr_sch": "cosineannealing", "T_max": 30, "warmup_ratio": 0.1},
+    "constant": {"lr": 1e-3, "lr_sch": "constant", "factor": 0.5, "total_iters": 3},
+    "onecycle": {"lr": 1e-3, "lr_sch": "onecycle", "steps_per_epoch": 7, "epochs": 3, "pct_start": 0.25},
+    "plateau_max": {"type": "adamw", "lr": 1e-3, "lr_sch": "plateau", "mode": "max", "monitor_metric": "acc"},
+}
+
+
+def make_opt():
+    """Optimizer / scheduler factory: the reference's own `OptModule` (src/opt/optimizer.py:1-173, imports
+    torch only) on a small nn.Linear for a table of `opt:` sections -> optimizer class and defaults, scheduler classes,
+    Lightning scheduler-config keys, and the learning-rate trace of 12 scheduler steps.  tests/golden/opt.json."""
+    import json
+
+    sys.path.insert(0, REF)
+    from src.opt.optimizer import OptModule as RefOpt
+
+    def describe(conf):
+        opt = conf["optimizer"] if isinstance(conf, dict) else conf
+        d = {"optimizer": type(opt).__name__, "lr": opt.defaults["lr"], "weight_decay": opt.defaults.get("weight_decay", 0)}
+        if isinstance(conf, dict):
+            sc = conf["lr_scheduler"]
+            sch = sc["scheduler"]
+            d["scheduler"] = type(sch).__name__
+            d["inner"] = [type(x).__name__ for x in getattr(sch, "_schedulers", [])]
+            d["keys"] = {k: v for k, v in sc.items() if k != "scheduler"}
+            trace = []
+            for i in range(12):
+                opt.step()
+                if sc.get("reduce_on_plateau"):
+                    sch.step(1.0 if sch.mode == "min" else 0.0)   # never improves -> reductions after `patience`
+                else:
+                    sch.step()
+                trace.append(opt.param_groups[0]["lr"])
+            d["lr_trace"] = trace
+        return d
+
+    out = {}
+    for name, cfg in OPT_CASES.items():
+        lin = torch.nn.Linear(4, 4)
+        out[name] = describe(RefOpt.from_config(dict(cfg))(lin))
+    # the module-level wrapper (src/basemodule.py:152-182): plateau needs data.val_path, one-cycle gets its run length
+    _import_reference()
+    from src.basemodule import BaseLightningModule as RefBase
+
+    class _Self:  # the attributes configure_optimizers reads
+        def __init__(self, config):
+            self.config, self.model, self.loss_name, self.monitor_metric = config, torch.nn.Linear(4, 4), "mae", "mae"
+
+    mod_cases = {
+        "plateau_no_val": {"opt": {"type": "AdamW", "lr": 1e-3, "lr_sch": "plateau"}, "data": {}},
+        "plateau_with_val": {"opt": {"type": "AdamW", "lr": 1e-3, "lr_sch": "plateau", "factor": 0.5}, "data": {"val_path": "x.h5"}},
+        "onecycle_run_length": {"opt": {"lr": 2e-3, "lr_sch": "onecycle"}, "data": {"num_samples": 1000},
+                                "train": {"batch_size": 48, "ep": 3}},
+        "no_scheduler": {"opt": {"lr": 1e-3}},
+    }
+    mod_out = {}
+    for name, cfg in mod_cases.items():
+        import copy
+        d = describe(RefBase.configure_optimizers(_Self(copy.deepcopy(cfg))))
+        if name == "onecycle_run_length":
+            d["total_steps"] = RefBase.configure_optimizers(_Self(copy.deepcopy(cfg)))["lr_scheduler"]["scheduler"].total_steps
+        mod_out[name] = d
+    path = os.path.join(ROOT, "tests", "golden", "opt.json")
+    with open(path, "w") as f:
+        json.dump({"cases": OPT_CASES, "expected": out, "module_cases": mod_cases, "module_expected": mod_out}, f, indent=1)
+    print(f"[opt] wrote {path}")
+
+def make_evalstats():
+    """Epoch-level regression statistics and the eval-step batch contract: the reference's own
+    `ViTLModule.on_validation_epoch_end` and `_shared_eval_step` (src/vit.py:94-125, 157-187), called unbound on an object
+    with the attributes they read (`torchmetrics`, absent here, is stubbed just far enough for `import src.vit`; the metric
+    objects the methods call are simple recorders).  Records: val_bias_median / val_p90 / val_beta for one and for three
+    targets, and which tensor of a 3- / 4-tuple batch reaches the model at noise_level 0 and > 0."""
+    import json
+
+    _import_reference()
+    if "torchmetrics" not in sys.modules:
+        tm = types.ModuleType("torchmetrics")
+        for n in ("Accuracy", "MeanAbsoluteError", "MeanSquaredError", "R2Score"):
+            setattr(tm, n, type(n, (object,), {}))
+        sys.modules["torchmetrics"] = tm
+    from src.vit import ViTLModule as RefModule, _normalize_task
+
+    rng = np.random.Generator(np.random.PCG64(123))
+    out = {"stats": {}, "tasks": {}}
+    for tag, ncol in (("one", 1), ("three", 3)):
+        lab = rng.random((50, ncol)).astype(np.float32)
+        pred = (0.1 + 0.8 * lab + 0.05 * rng.standard_normal((50, ncol))).astype(np.float32)
+        if ncol == 1:
+            lab, pred = lab[:, 0], pred[:, 0]
+        logged = {}
+
+        class Host:
+            task_type = "reg"
+            val_dict = {"preds": [torch.from_numpy(pred[:20]), torch.from_numpy(pred[20:])],
+                        "labels": [torch.from_numpy(lab[:20]), torch.from_numpy(lab[20:])]}
+
+            def log(self, name, value, **kw):
+                logged[name] = float(value)
+
+        RefModule.on_validation_epoch_end(Host())
+        out["stats"][tag] = {"pred": pred.tolist(), "label": lab.tolist(), "logged": logged}
+    for cfg in ({"model": {"task_type": "reg"}}, {"model": {"task": "Classification"}}, {"model": {}}, {"model": {"task_type": "cls"}},
+                {"model": {"task_type": "regression"}}):
+        out["tasks"][json.dumps(cfg)] = _normalize_task(cfg)
+
+    # which tensor reaches the model
+    seen = {}
+    for nl in (0.0, 0.3):
+        for n_items in (3, 4):
+            class Out:
+                loss = torch.tensor(0.5)
+                logits = torch.zeros(4, 1)
+
+            class Host2:
+                task_type, noise_level, loss_name = "reg", nl, "mae"
+
+                def forward(self, x, labels, loss_only=True):
+                    seen[f"nl{nl}_n{n_items}"] = float(x[0, 0])
+                    return Out()
+
+                def log(self, *a, **k):
+                    pass
+
+                mae = mse = r2 = staticmethod(lambda p, t: torch.tensor(0.0))
+
+            noisy, flux, err, lab4 = torch.full((4, 8), 9.0), torch.full((4, 8), 1.0), torch.ones(4, 8), torch.zeros(4)
+            batch = (noisy, flux, err, lab4) if n_items == 4 else (flux, err, lab4)
+            RefModule._shared_eval_step(Host2(), batch, "val")
+    out["eval_input"] = seen  # 9.0 = the pre-generated noisy copy, 1.0 = the clean flux
+    path = os.path.join(ROOT, "tests", "golden", "evalstats.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[evalstats] wrote {path}: {out['eval_input']} {out['tasks']}")
+
 
 def main():
     torch.manual_seed(0)
@@ -565,6 +707,8 @@ def main():
     make_prep()
     make_conv()
     make_data()
+    make_opt()
+    make_evalstats()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -575,7 +719,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

@@ -148,3 +148,50 @@ def test_metrics_against_scikit_learn():
     for a in range(0, 300, 64):
         acc(torch.from_numpy(logits[a:a + 64]), torch.from_numpy(y[a:a + 64]))
     assert abs(float(acc.compute()) - sk.accuracy_score(y, logits.argmax(1))) < 1e-7
+
+
+def _evalstats():
+    import json
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "evalstats.json")) as f:
+        return json.load(f)
+
+
+def test_epoch_statistics_and_eval_contract_match_reference_module():
+    """tests/golden/evalstats.json: the reference's own `ViTLModule.on_validation_epoch_end`, `_shared_eval_step` and
+    `_normalize_task` (src/vit.py:20-27, 94-125, 157-187), called unbound on recorder objects by oracle/make_golden.py.
+    The rewritten module must log the same val_bias_median / val_p90 / val_beta (one and three targets), pick the same
+    tensor of a 3- / 4-tuple batch as the model input at noise_level 0 and > 0, and resolve the task the same way."""
+    import json
+
+    from vit_amd.module import ViTLModule, _normalize_task
+
+    doc = _evalstats()
+    for cfg_json, want in doc["tasks"].items():
+        assert _normalize_task(json.loads(cfg_json)) == want, cfg_json
+    for tag, rec in doc["stats"].items():
+        pred, lab = torch.tensor(rec["pred"]), torch.tensor(rec["label"])
+        logged = {}
+
+        class Host:
+            task_type = "reg"
+            val_dict = {"preds": [pred[:20], pred[20:]], "labels": [lab[:20], lab[20:]]}
+            _residual_stats = staticmethod(ViTLModule._residual_stats)
+
+            def log(self, name, value, **kw):
+                logged[name] = float(value)
+
+        ViTLModule.on_validation_epoch_end(Host())
+        assert logged.keys() == rec["logged"].keys(), (sorted(logged), sorted(rec["logged"]))
+        for k, v in rec["logged"].items():
+            assert abs(logged[k] - v) <= 2e-6 * max(1.0, abs(v)), (tag, k, logged[k], v)
+    noisy, flux, err, lab4 = torch.full((4, 8), 9.0), torch.full((4, 8), 1.0), torch.ones(4, 8), torch.zeros(4)
+    for key, want in doc["eval_input"].items():
+        nl, n_items = float(key.split("_")[0][2:]), int(key.split("_n")[1])
+
+        class Host2:
+            noise_level = nl
+
+        batch = (noisy, flux, err, lab4) if n_items == 4 else (flux, err, lab4)
+        x, labels = ViTLModule._eval_inputs(Host2(), batch)
+        assert float(x[0, 0]) == want and labels is lab4, key

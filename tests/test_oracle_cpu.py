@@ -325,3 +325,71 @@ def test_spec_dataset_matches_reference_dataset_classes(tag, norm):
     assert torch.allclose(item_va[3], torch.from_numpy(g[f"{key}_item_va_label"]), atol=1e-6)
     assert torch.allclose(item_tr[2], torch.from_numpy(g[f"{key}_item_tr_label"]), atol=1e-6)
     assert tr.noisy is None  # training: noise is drawn on the device per step (vit.py:86-88), not stored
+
+
+def _opt_cases():
+    import json
+
+    with open(os.path.join(GOLD, "opt.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_opt_cases()["cases"]))
+def test_optmodule_matches_reference_optmodule(name):
+    """tests/golden/opt.json: what the reference's own `OptModule.from_config(cfg)(model)` (src/opt/optimizer.py:37-172) builds
+    for a table of `opt:` sections -- optimizer class and defaults, scheduler classes (incl. the LinearLR warm-up inside a
+    SequentialLR), the Lightning scheduler-config keys, and the learning-rate trace of 12 scheduler steps."""
+    from vit_amd.optimizer import OptModule
+
+    doc = _opt_cases()
+    cfg, want = dict(doc["cases"][name]), doc["expected"][name]
+    conf = OptModule.from_config(cfg)(torch.nn.Linear(4, 4))
+    opt = conf["optimizer"] if isinstance(conf, dict) else conf
+    assert type(opt).__name__ == want["optimizer"]
+    assert opt.defaults["lr"] == want["lr"] and opt.defaults.get("weight_decay", 0) == want["weight_decay"]
+    assert isinstance(conf, dict) == ("scheduler" in want)
+    if "scheduler" in want:
+        sc = conf["lr_scheduler"]
+        sch = sc["scheduler"]
+        assert type(sch).__name__ == want["scheduler"]
+        assert [type(x).__name__ for x in getattr(sch, "_schedulers", [])] == want["inner"]
+        assert {k: v for k, v in sc.items() if k != "scheduler"} == want["keys"]
+        trace = []
+        for _ in range(12):
+            opt.step()
+            if sc.get("reduce_on_plateau"):
+                sch.step(1.0 if sch.mode == "min" else 0.0)
+            else:
+                sch.step()
+            trace.append(opt.param_groups[0]["lr"])
+        assert trace == pytest.approx(want["lr_trace"], rel=1e-12, abs=0)
+
+
+@pytest.mark.parametrize("name", sorted(_opt_cases()["module_cases"]))
+def test_configure_optimizers_matches_reference_module(name):
+    """The reference's own `BaseLightningModule.configure_optimizers` (src/basemodule.py:152-182), called on an object with
+    the attributes it reads: a plateau scheduler is dropped without data.val_path, a one-cycle scheduler gets
+    steps_per_epoch = ceil(num_samples / batch_size) and epochs = train.ep.  Same function here, same outcome."""
+    import copy
+    import warnings
+
+    from vit_amd.module import BaseLightningModule
+
+    doc = _opt_cases()
+    cfg, want = copy.deepcopy(doc["module_cases"][name]), doc["module_expected"][name]
+
+    class Host:
+        config, model, loss_name, monitor_metric = cfg, torch.nn.Linear(4, 4), "mae", "mae"
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        conf = BaseLightningModule.configure_optimizers(Host())
+    opt = conf["optimizer"] if isinstance(conf, dict) else conf
+    assert type(opt).__name__ == want["optimizer"] and opt.defaults["lr"] == want["lr"]
+    assert isinstance(conf, dict) == ("scheduler" in want)
+    if "scheduler" in want:
+        sc = conf["lr_scheduler"]
+        assert type(sc["scheduler"]).__name__ == want["scheduler"]
+        assert {k: v for k, v in sc.items() if k != "scheduler"} == want["keys"]
+        if "total_steps" in want:
+            assert sc["scheduler"].total_steps == want["total_steps"]
