@@ -683,6 +683,44 @@ def make_evalstats():
         json.dump(out, f)
     print(f"[evalstats] wrote {path}: {out['eval_input']} {out['tasks']}")
 
+NAME_CASES = [
+    dict(patch_size=32, hidden_size=32, num_hidden_layers=3, num_attention_heads=2, stride_size=32, stride_ratio=1, proj_fn="SW", noise=0),
+    dict(patch_size=256, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, stride_size=None, stride_ratio=0.5, proj_fn="C1D", noise=0.5),
+    dict(patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, stride_size=0, stride_ratio=1, proj_fn="CNN", noise=1.25),
+]
+WARM_CASES = [
+    ("zca", dict(r=16, shrinkage=0.2, freeze_epochs=5)), ("zca", dict(freeze_epochs=-1, bias=False)), ("zca", dict(r=None, shrinkage=0.0)),
+    ("pca", dict(r=8)), ("pca", dict(r=None, bias=False, freeze_epochs=3)),
+    ("attention", dict(r=8, freeze_epochs=2)), ("attention", dict(scale_by_eigvals=False)),
+]
+
+
+def make_names():
+    """Run names (checkpoints and logs are named after them): the reference's own `build_model_name`
+    (src/models/model_utils.py:9-45) and the name prefix / output width its `_build_preprocessor` gives each `warmup:` variant
+    (src/models/builder.py:45-133) on synthetic covariance statistics.  tests/golden/names.json."""
+    import json
+
+    _import_reference()
+    from src.models.builder import _build_preprocessor as ref_build
+    from src.models.model_utils import build_model_name as ref_name
+
+    out = {"names": [], "warm": []}
+    for c in NAME_CASES:
+        ns = types.SimpleNamespace(**{k: v for k, v in c.items() if k != "noise"})
+        out["names"].append({"case": c, "ViT": ref_name(ns, "ViT", full_config={"noise": {"noise_level": c["noise"]}}),
+                             "plain": ref_name(ns, "ZCA_ViT")})
+    g = torch.Generator().manual_seed(3)
+    q, _ = torch.linalg.qr(torch.randn(64, 64, generator=g))
+    stats = {"eigvecs": q, "eigvals": torch.logspace(0, -2, 64), "mean": torch.randn(64, generator=g)}
+    for kind, warm in WARM_CASES:
+        pre, out_dim, prefix, _desc = ref_build(kind, dict(warm), stats, 64, warm.get("freeze_epochs", 0) != 0)
+        out["warm"].append({"kind": kind, "warmup": warm, "prefix": prefix, "out_dim": int(out_dim)})
+    path = os.path.join(ROOT, "tests", "golden", "names.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(f"[names] wrote {path}: " + ", ".join(w["prefix"] for w in out["warm"]))
+
 
 def main():
     torch.manual_seed(0)
@@ -709,6 +747,7 @@ def main():
     make_data()
     make_opt()
     make_evalstats()
+    make_names()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -719,7 +758,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

@@ -195,3 +195,27 @@ def test_epoch_statistics_and_eval_contract_match_reference_module():
         batch = (noisy, flux, err, lab4) if n_items == 4 else (flux, err, lab4)
         x, labels = ViTLModule._eval_inputs(Host2(), batch)
         assert float(x[0, 0]) == want and labels is lab4, key
+
+
+def test_run_names_match_reference():
+    """tests/golden/names.json: the reference's own `build_model_name` (src/models/model_utils.py:9-45) and the prefix / output
+    width of its `_build_preprocessor` (src/models/builder.py:45-133) for each `warmup:` variant."""
+    import json
+    import types
+
+    from vit_amd.builder import _build_preprocessor
+    from vit_amd.specvit import build_model_name
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "names.json")) as f:
+        doc = json.load(f)
+    for rec in doc["names"]:
+        c = rec["case"]
+        ns = types.SimpleNamespace(**{k: v for k, v in c.items() if k != "noise"})
+        assert build_model_name(ns, "ViT", full_config={"noise": {"noise_level": c["noise"]}}) == rec["ViT"]
+        assert build_model_name(ns, "ZCA_ViT") == rec["plain"]
+    g = torch.Generator().manual_seed(3)
+    q, _ = torch.linalg.qr(torch.randn(64, 64, generator=g))
+    stats = {"eigvecs": q, "eigvals": torch.logspace(0, -2, 64), "mean": torch.randn(64, generator=g)}
+    for rec in doc["warm"]:
+        _, out_dim, prefix = _build_preprocessor(rec["kind"], dict(rec["warmup"]), stats)
+        assert (prefix, out_dim) == (rec["prefix"], rec["out_dim"]), rec
