@@ -45,16 +45,19 @@ class SequenceClassifierOutput:
 
 
 def build_model_name(config, model_prefix: str = "ViT", full_config: dict = None) -> str:
-    """Run-name rule of src/models/model_utils.py:9-45."""
-    stride_used = getattr(config, "stride_size", None)
-    stride_tag = int(stride_used) if (stride_used is not None and stride_used) else config.stride_ratio
-    base_name = (f"{model_prefix}_p{config.patch_size}_h{config.hidden_size}_l{config.num_hidden_layers}_"
-                 f"a{config.num_attention_heads}_s{stride_tag}_p{config.proj_fn}")
-    if full_config is not None:
-        noise_level = (full_config.get("noise", {}) or {}).get("noise_level", 0)
-        if noise_level > 0:
-            base_name += f"_nz{str(noise_level).replace('.', '')}"
-    return base_name
+    """Run name `{prefix}_p{patch}_h{hidden}_l{layers}_a{heads}_s{stride}_p{proj_fn}[_nz{noise digits}]` -- the rule of
+    src/models/model_utils.py:9-45 (pinned by tests/golden/names.json).  The stride tag is the explicit `stride_size` when
+    one is set (truthy), else the `stride_ratio`; a positive noise level is appended with its decimal point removed."""
+    explicit = getattr(config, "stride_size", None)
+    fields = [
+        ("p", config.patch_size), ("h", config.hidden_size), ("l", config.num_hidden_layers),
+        ("a", config.num_attention_heads), ("s", int(explicit) if explicit else config.stride_ratio), ("p", config.proj_fn),
+    ]
+    name = "_".join([model_prefix] + [f"{tag}{value}" for tag, value in fields])
+    level = ((full_config or {}).get("noise") or {}).get("noise_level", 0)
+    if level and level > 0:
+        name += "_nz" + str(level).replace(".", "")
+    return name
 
 
 class _Node(nn.Module):
