@@ -225,7 +225,51 @@ class FusedAdamW(torch.optim.Optimizer):
                     grp[k] = tuple(v) if k == "betas" else v
 
 
+# ---------------------------------------------------------------------------------------------------------------- factory
+_OPTIMIZERS = {
+    "adam": "Adam", "adamw": "AdamW", "sgd": "SGD", "rmsprop": "RMSprop", "adadelta": "Adadelta", "adagrad": "Adagrad",
+    "adamax": "Adamax", "asgd": "ASGD", "lbfgs": "LBFGS", "rprop": "Rprop", "sparseadam": "SparseAdam",
+}
+_SCHEDULERS = {
+    "cosine": "CosineAnnealingLR", "cosineannealing": "CosineAnnealingLR", "cosineannealinglr": "CosineAnnealingLR",
+    "onecycle": "OneCycleLR", "constant": "ConstantLR", "constantlr": "ConstantLR", "plateau": "ReduceLROnPlateau",
+}
+
+
+def _family(name: str) -> str:
+    """Which argument rules a scheduler name falls under (substring match, first hit wins, as the reference resolves it)."""
+    for fam in ("cosine", "onecycle", "constant", "plateau"):
+        if fam in name:
+            return fam
+    return ""
+
+
+# per family: (required arguments as {kwarg: how to get it}, optional keys copied only when present in the config)
+def _scheduler_kwargs(fam: str, cfg: dict, lr: float) -> dict:
+    if fam == "cosine":
+        kw = {"T_max": cfg.get("T_max", cfg.get("ep", 100))}
+        optional = ("eta_min",)
+    elif fam == "onecycle":  # the run length (steps_per_epoch, epochs) is injected by configure_optimizers
+        kw = {"max_lr": lr}
+        optional = ("steps_per_epoch", "epochs", "pct_start", "div_factor", "final_div_factor")
+    elif fam == "constant":
+        kw = {"factor": cfg.get("factor", 1.0), "total_iters": cfg.get("total_iters", 1)}
+        optional = ()
+    elif fam == "plateau":
+        kw = {"factor": cfg.get("factor", 0.1), "patience": cfg.get("patience", 10)}
+        optional = ("mode",)
+    else:
+        return {}
+    kw.update({k: cfg[k] for k in optional if k in cfg})
+    return kw
+
+
 class OptModule:
+    """The optimizer / scheduler factory behind `configure_optimizers` (reference: src/opt/optimizer.py:1-173).  Same config
+    keys (`lr`, `type`, `weight_decay`, `lr_sch`, `warmup.{ratio,epochs}` / `warmup_ratio` / `warmup_epochs`, the scheduler's
+    own keys), same result shape (an optimizer, or Lightning's {"optimizer", "lr_scheduler": {scheduler, monitor, ...}});
+    behaviour pinned case by case on the reference's class in tests/golden/opt.json."""
+
     def __init__(self, lr, monitor_metric="loss", opt_type="adam", weight_decay=0.0, lr_scheduler_name=None,
                  warmup_ratio=0.0, warmup_epochs=None, **kwargs) -> None:
         self.lr = float(lr)
@@ -236,90 +280,64 @@ class OptModule:
         self.warmup_ratio = warmup_ratio
         self.warmup_epochs = warmup_epochs
         self.kwargs = kwargs
-        o = torch.optim
-        self.opt_fns = {
-            "adam": o.Adam, "adamw": o.AdamW, "sgd": o.SGD, "rmsprop": o.RMSprop, "adadelta": o.Adadelta,
-            "adagrad": o.Adagrad, "adamax": o.Adamax, "asgd": o.ASGD, "lbfgs": o.LBFGS, "rprop": o.Rprop,
-            "sparseadam": o.SparseAdam,
-        }
-        s = torch.optim.lr_scheduler
-        self.lr_schedulers = {
-            "cosine": s.CosineAnnealingLR, "cosineannealing": s.CosineAnnealingLR, "cosineannealinglr": s.CosineAnnealingLR,
-            "onecycle": s.OneCycleLR, "constant": s.ConstantLR, "constantlr": s.ConstantLR, "plateau": s.ReduceLROnPlateau,
-        }
+        self.opt_fns = {k: getattr(torch.optim, v) for k, v in _OPTIMIZERS.items()}
+        self.lr_schedulers = {k: getattr(torch.optim.lr_scheduler, v) for k, v in _SCHEDULERS.items()}
 
     @classmethod
     def from_config(cls, config):
-        """Same key handling as the reference (optimizer.py:37-105)."""
         lr = config.get("lr", 1e-3)
-        opt_type = config.get("type", "adam").lower()
-        weight_decay = config.get("weight_decay", 0)
-        monitor_metric = config.get("monitor_metric", "loss")
-        warmup_config = config.get("warmup", {})
-        warmup_ratio = warmup_config.get("ratio", config.get("warmup_ratio", 0.0))
-        warmup_epochs = warmup_config.get("epochs", config.get("warmup_epochs", None))
-        if "lr_sch" in config:
-            name = config["lr_sch"].lower()
-            kwargs = {}
-            if "cosine" in name:
-                kwargs["T_max"] = config.get("T_max", config.get("ep", 100))
-                if "eta_min" in config:
-                    kwargs["eta_min"] = config["eta_min"]
-            elif "onecycle" in name:
-                kwargs["max_lr"] = lr
-                for k in ("steps_per_epoch", "epochs", "pct_start", "div_factor", "final_div_factor"):
-                    if k in config:
-                        kwargs[k] = config[k]
-            elif "constant" in name:
-                kwargs["factor"] = config.get("factor", 1.0)
-                kwargs["total_iters"] = config.get("total_iters", 1)
-            elif "plateau" in name:
-                kwargs["factor"] = config.get("factor", 0.1)
-                kwargs["patience"] = config.get("patience", 10)
-                if "mode" in config:
-                    kwargs["mode"] = config["mode"]
-            return cls(lr=lr, monitor_metric=monitor_metric, opt_type=opt_type, weight_decay=weight_decay,
-                       lr_scheduler_name=name, warmup_ratio=warmup_ratio, warmup_epochs=warmup_epochs, **kwargs)
-        return cls(lr=lr, monitor_metric=monitor_metric, opt_type=opt_type, weight_decay=weight_decay,
-                   warmup_ratio=warmup_ratio, warmup_epochs=warmup_epochs)
+        warm = config.get("warmup", {})
+        common = dict(
+            lr=lr, monitor_metric=config.get("monitor_metric", "loss"), opt_type=config.get("type", "adam").lower(),
+            weight_decay=config.get("weight_decay", 0),
+            warmup_ratio=warm.get("ratio", config.get("warmup_ratio", 0.0)),
+            warmup_epochs=warm.get("epochs", config.get("warmup_epochs", None)),
+        )
+        if "lr_sch" not in config:
+            return cls(**common)
+        name = config["lr_sch"].lower()
+        return cls(lr_scheduler_name=name, **common, **_scheduler_kwargs(_family(name), config, lr))
 
     def _make_optimizer(self, model):
         from .specvit import MyViT
 
-        if self.opt_type in ("adam", "adamw") and isinstance(model, MyViT):
-            # torch.optim.Adam's weight_decay is L2-in-gradient; the reference passes weight_decay=0 by default
-            # (optimizer.py:51), where Adam == AdamW.  A non-zero decay with 'adam' keeps torch's own implementation.
-            if self.opt_type == "adamw" or not self.weight_decay:
-                return FusedAdamW(model, lr=self.lr, weight_decay=self.weight_decay)
+        fused_ok = self.opt_type == "adamw" or (self.opt_type == "adam" and not self.weight_decay)
+        if isinstance(model, MyViT) and fused_ok:
+            # torch.optim.Adam's weight_decay is L2-in-the-gradient; with the reference's default weight_decay=0
+            # (optimizer.py:51) Adam == AdamW, and only then does 'adam' take the fused kernel
+            return FusedAdamW(model, lr=self.lr, weight_decay=self.weight_decay)
         return self.opt_fns[self.opt_type](model.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+
+    def _warmup_length(self) -> Optional[int]:
+        """Epochs of linear warm-up in front of the scheduler, or None.  One-cycle brings its own."""
+        wanted = self.warmup_ratio > 0 or self.warmup_epochs is not None
+        if not wanted or "onecycle" in self.lr_scheduler_name:
+            return None
+        if self.warmup_epochs is not None:
+            return self.warmup_epochs
+        horizon = self.kwargs.get("T_max", self.kwargs.get("epochs", 100))
+        return max(1, int(horizon * self.warmup_ratio))
 
     def __call__(self, model):
         optimizer = self._make_optimizer(model)
-        if self.lr_scheduler_name is None:
+        name = self.lr_scheduler_name
+        if name is None:
             return optimizer
-        if self.lr_scheduler_name not in self.lr_schedulers:
-            raise ValueError(f"Unknown scheduler: {self.lr_scheduler_name}")
-        use_warmup = (self.warmup_ratio > 0 or self.warmup_epochs is not None) and "onecycle" not in self.lr_scheduler_name
-        if use_warmup:
-            if self.warmup_epochs is not None:
-                warmup_epochs = self.warmup_epochs
-            else:
-                total_epochs = self.kwargs.get("T_max", self.kwargs.get("epochs", 100))
-                warmup_epochs = max(1, int(total_epochs * self.warmup_ratio))
-            warm = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=0.1, total_iters=warmup_epochs)
-            main = self.lr_schedulers[self.lr_scheduler_name](optimizer, **self.kwargs)
-            scheduler = torch.optim.lr_scheduler.SequentialLR(optimizer, schedulers=[warm, main], milestones=[warmup_epochs])
-            print(f"[Warmup] Using {warmup_epochs} warmup epochs before {self.lr_scheduler_name}")
+        if name not in self.lr_schedulers:
+            raise ValueError(f"Unknown scheduler: {name}")
+        sched_mod = torch.optim.lr_scheduler
+        n_warm = self._warmup_length()
+        if n_warm is None:
+            scheduler = self.lr_schedulers[name](optimizer, **self.kwargs)
+        else:  # LinearLR from 10 % of the target rate, then the scheduler proper (constructed in this order: each
+            # constructor records / touches the optimizer's learning rate)
+            ramp = sched_mod.LinearLR(optimizer, start_factor=0.1, total_iters=n_warm)
+            main = self.lr_schedulers[name](optimizer, **self.kwargs)
+            scheduler = sched_mod.SequentialLR(optimizer, schedulers=[ramp, main], milestones=[n_warm])
+        entry = {"scheduler": scheduler, "monitor": f"val_{self.monitor_metric}"}
+        fam = _family(name)
+        if fam == "plateau":
+            entry.update(reduce_on_plateau=True, strict=False)  # Lightning: step after validation, tolerate a missing metric
         else:
-            scheduler = self.lr_schedulers[self.lr_scheduler_name](optimizer, **self.kwargs)
-        scheduler_config = {"scheduler": scheduler, "monitor": f"val_{self.monitor_metric}"}
-        if "plateau" in self.lr_scheduler_name:
-            scheduler_config["reduce_on_plateau"] = True
-            scheduler_config["strict"] = False
-        elif "onecycle" in self.lr_scheduler_name:
-            scheduler_config["interval"] = "step"
-            scheduler_config["frequency"] = 1
-        else:
-            scheduler_config["interval"] = "epoch"
-            scheduler_config["frequency"] = 1
-        return {"optimizer": optimizer, "lr_scheduler": scheduler_config}
+            entry.update(interval="step" if fam == "onecycle" else "epoch", frequency=1)
+        return {"optimizer": optimizer, "lr_scheduler": entry}
