@@ -721,6 +721,36 @@ def make_names():
         json.dump(out, f, indent=1)
     print(f"[names] wrote {path}: " + ", ".join(w["prefix"] for w in out["warm"]))
 
+CONFIG_CASES = {
+    "reg_one": {"model": dict(task_type="reg", image_size=4096, patch_size=32, hidden_size=32, num_hidden_layers=3, num_attention_heads=2, stride_size=32, proj_fn="SW"), "data": {"param": "log_g"}},
+    "reg_three_str": {"model": dict(task_type="reg", image_size=1000, patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, stride_ratio=0.5, proj_fn="C1D", num_labels=7), "data": {"param": "T_eff, log_g ,M_H"}},
+    "reg_list": {"model": dict(task_type="regression", image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=1, num_attention_heads=2, proj_fn="SW"), "data": {"param": ["a", "b"]}},
+    "reg_no_param": {"model": dict(task_type="reg", image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=1, num_attention_heads=2, proj_fn="SW", num_labels=4), "data": {}},
+    "cls": {"model": dict(task_type="cls", image_size=512, patch_size=32, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, stride_size=16, proj_fn="SW", num_labels=5, pos_encoding_type="learned", max_position_embeddings=64, rope_base=500.0)},
+}
+
+
+def make_config():
+    """`get_vit_config` (SURVEY 8 row a4): the reference's own function (src/models/builder.py:200-258) on a table of configs;
+    the fields the path reads, plus the `num_labels` it writes back into config['model'].  tests/golden/config.json."""
+    import copy
+    import json
+
+    get_vit_config, _, _ = _import_reference()
+    fields = ["task_type", "image_size", "patch_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "proj_fn",
+              "stride_ratio", "stride_size", "num_labels", "num_channels", "hidden_act", "hidden_dropout_prob",
+              "attention_probs_dropout_prob", "layer_norm_eps", "qkv_bias", "intermediate_size", "pos_encoding_type",
+              "max_position_embeddings", "rope_base", "initializer_range"]
+    out = {}
+    for name, cfg in CONFIG_CASES.items():
+        c = copy.deepcopy(cfg)
+        vc = get_vit_config(c)
+        out[name] = {"fields": {k: getattr(vc, k, None) for k in fields}, "written_back_num_labels": c["model"].get("num_labels")}
+    path = os.path.join(ROOT, "tests", "golden", "config.json")
+    with open(path, "w") as f:
+        json.dump({"cases": CONFIG_CASES, "expected": out}, f, indent=1)
+    print(f"[config] wrote {path}")
+
 
 def main():
     torch.manual_seed(0)
@@ -748,6 +778,7 @@ def main():
     make_opt()
     make_evalstats()
     make_names()
+    make_config()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -758,7 +789,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

@@ -219,3 +219,24 @@ def test_run_names_match_reference():
     for rec in doc["warm"]:
         _, out_dim, prefix = _build_preprocessor(rec["kind"], dict(rec["warmup"]), stats)
         assert (prefix, out_dim) == (rec["prefix"], rec["out_dim"]), rec
+
+
+def test_get_vit_config_matches_reference_function():
+    """tests/golden/config.json: the reference's own `get_vit_config` (src/models/builder.py:200-258) on a table of configs --
+    every field the path reads (incl. the hard-coded dropout / eps / activation / 4x MLP width) and the `num_labels` it writes
+    back into config['model'] (regression: always derived from data.param)."""
+    import copy
+    import json
+
+    from vit_amd.config import get_vit_config
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "config.json")) as f:
+        doc = json.load(f)
+    for name, cfg in doc["cases"].items():
+        c = copy.deepcopy(cfg)
+        vc = get_vit_config(c)
+        want = doc["expected"][name]
+        for k, v in want["fields"].items():
+            got = getattr(vc, k)
+            assert got == v or (v is None and got is None), (name, k, got, v)
+        assert c["model"].get("num_labels") == want["written_back_num_labels"], name

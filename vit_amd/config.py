@@ -64,40 +64,36 @@ class ViTConfig:
         return self.hidden_size // self.num_attention_heads
 
 
+def _targets_in(param) -> int:
+    """How many regression targets `data.param` names: a comma-separated string or a list; anything else (None, '', []) = 1."""
+    if isinstance(param, str):
+        names = [tok for tok in (piece.strip() for piece in param.split(",")) if tok]
+        return len(names) or 1
+    if isinstance(param, (list, tuple)):
+        return len(param) or 1
+    return 1
+
+
 def get_vit_config(config) -> ViTConfig:
-    """Build the model config from the YAML dict; same rules as the reference (builder.py:200-258): for regression
-    `num_labels` is ALWAYS derived from data.param (and written back into config['model']), with the same warning."""
-    m = config["model"]
-    d = config.get("data", {}) or {}
-    task = (m.get("task_type") or m.get("task") or "cls").lower()
+    """The model config from the YAML dict (reference: src/models/builder.py:200-258, pinned on it by
+    tests/golden/config.json).  Regression: `num_labels` ALWAYS follows `data.param` -- a conflicting `model.num_labels` is
+    overridden with a warning -- and is written back into config['model']; classification takes `model.num_labels`."""
+    import warnings
+
+    model = config["model"]
+    task = str(model.get("task_type") or model.get("task") or "cls").lower()
     if task in ("reg", "regression"):
-        p = d.get("param", None)
-        num_labels = 1
-        if isinstance(p, str) and len(p) > 0:
-            plist = [x.strip() for x in p.split(",") if x.strip()]
-            if len(plist) >= 1:
-                num_labels = len(plist)
-        elif isinstance(p, (list, tuple)) and len(p) > 0:
-            num_labels = len(p)
-        config_num_labels = m.get("num_labels")
-        if config_num_labels is not None and int(config_num_labels) != num_labels:
-            print(f"Warning: model.num_labels={config_num_labels} conflicts with data.param (which implies "
-                  f"{num_labels} labels). Using {num_labels} from data.param.")
-        m["num_labels"] = num_labels
+        num_labels = _targets_in((config.get("data") or {}).get("param"))
+        stated = model.get("num_labels")
+        if stated is not None and int(stated) != num_labels:
+            warnings.warn(f"model.num_labels={stated} disagrees with data.param, which names {num_labels} target(s); "
+                          f"using {num_labels}", stacklevel=2)
+        model["num_labels"] = num_labels
     else:
-        num_labels = int(m.get("num_labels", 1) or 1)
+        num_labels = int(model.get("num_labels", 1) or 1)
+    optional = {k: model[k] for k in ("stride_ratio", "stride_size", "pos_encoding_type", "max_position_embeddings", "rope_base")
+                if k in model}
     return ViTConfig(
-        task_type=m["task_type"],
-        image_size=m["image_size"],
-        patch_size=m["patch_size"],
-        hidden_size=m["hidden_size"],
-        num_hidden_layers=m["num_hidden_layers"],
-        num_attention_heads=m["num_attention_heads"],
-        stride_ratio=m.get("stride_ratio", 1),
-        stride_size=m.get("stride_size", None),
-        proj_fn=m["proj_fn"],
-        num_labels=num_labels,
-        pos_encoding_type=m.get("pos_encoding_type", None),
-        max_position_embeddings=m.get("max_position_embeddings", 512),
-        rope_base=m.get("rope_base", 10000.0),
-    )
+        task_type=model["task_type"], image_size=model["image_size"], patch_size=model["patch_size"],
+        hidden_size=model["hidden_size"], num_hidden_layers=model["num_hidden_layers"],
+        num_attention_heads=model["num_attention_heads"], proj_fn=model["proj_fn"], num_labels=num_labels, **optional)
