@@ -751,6 +751,41 @@ def make_config():
         json.dump({"cases": CONFIG_CASES, "expected": out}, f, indent=1)
     print(f"[config] wrote {path}")
 
+def make_freeze():
+    """Freeze schedule of the input preprocessor: the reference's own `PreprocessorFreezeCallback`
+    (src/prepca/callbacks.py) driven by recorder objects over 5 epochs for freeze_epochs in {0, 1, 3, -1}: which
+    `set_preprocessor_trainable(...)` calls it makes and when.  tests/golden/freeze.json."""
+    import json
+
+    _import_reference()
+    from src.prepca.callbacks import PreprocessorFreezeCallback
+
+    out = {}
+    for fe in (0, 1, 3, -1):
+        calls = []
+
+        class Model:
+            def set_preprocessor_trainable(self, flag):
+                calls.append([tr.current_epoch, bool(flag)])
+
+        class Trainer:
+            current_epoch = -1
+
+        class Module:
+            model = Model()
+
+        tr, mod = Trainer(), Module()
+        cb = PreprocessorFreezeCallback(freeze_epochs=fe)
+        cb.on_train_start(tr, mod)
+        for ep in range(5):
+            tr.current_epoch = ep
+            cb.on_train_epoch_start(tr, mod)
+        out[str(fe)] = calls
+    path = os.path.join(ROOT, "tests", "golden", "freeze.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"[freeze] wrote {path}: {out}")
+
 
 def main():
     torch.manual_seed(0)
@@ -779,6 +814,7 @@ def main():
     make_evalstats()
     make_names()
     make_config()
+    make_freeze()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -789,7 +825,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

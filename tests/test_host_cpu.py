@@ -240,3 +240,27 @@ def test_get_vit_config_matches_reference_function():
             got = getattr(vc, k)
             assert got == v or (v is None and got is None), (name, k, got, v)
         assert c["model"].get("num_labels") == want["written_back_num_labels"], name
+
+
+def test_freeze_schedule_matches_reference_callback():
+    """tests/golden/freeze.json: the calls the reference's own `PreprocessorFreezeCallback` (src/prepca/callbacks.py) makes to
+    `model.set_preprocessor_trainable` over 5 epochs, for freeze_epochs 0 / 1 / 3 / -1."""
+    import json
+
+    from vit_amd.trainer import FreezeSchedule
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "freeze.json")) as f:
+        doc = json.load(f)
+    for fe, want in doc.items():
+        calls, epoch = [], [-1]
+
+        class Model:
+            def set_preprocessor_trainable(self, flag):
+                calls.append([epoch[0], bool(flag)])
+
+        sch, m = FreezeSchedule(int(fe)), Model()
+        sch.on_train_start(m)
+        for ep in range(5):
+            epoch[0] = ep
+            sch.on_epoch_start(m, ep)
+        assert calls == want, (fe, calls, want)

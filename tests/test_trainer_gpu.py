@@ -167,13 +167,13 @@ def test_freeze_schedule_unfreezes_preprocessor(dev, tmp_path):
     assert torch.equal(e0[0][3], e1[0][3])                # untouched while frozen
     w = pre.linear.weight
     assert isinstance(w, torch.nn.Parameter) and w.requires_grad and w.grad is not None and float(w.grad.abs().sum()) > 0
-    assert trainer._unfrozen
+    assert trainer.freeze.released
     # permanent freeze never unfreezes
     cfg["warmup"]["freeze_epochs"] = -1
     cfg["model"]["image_size"] = 4096
     module2, trainer2 = make(cfg)
     trainer2.fit(module2, Batches(16, 1), Batches(16, 2))
-    assert module2.model.name.startswith("PCA64_fzperm") and module2.model.preprocessor._is_frozen and not trainer2._unfrozen
+    assert module2.model.name.startswith("PCA64_fzperm") and module2.model.preprocessor._is_frozen and not trainer2.freeze.released
 
 
 def test_save_resume_and_eval_only(dev, tmp_path, monkeypatch):

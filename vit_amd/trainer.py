@@ -34,7 +34,7 @@ import torch
 from . import ddp as ddp_mod
 from .optimizer import FusedAdamW
 
-__all__ = ["Trainer", "Checkpointer", "select_accelerator_and_devices", "get_training_strategy", "seed_everything"]
+__all__ = ["Trainer", "Checkpointer", "FreezeSchedule", "select_accelerator_and_devices", "get_training_strategy", "seed_everything"]
 
 
 def select_accelerator_and_devices(num_gpus: Optional[int] = None):
@@ -128,6 +128,29 @@ def model_state_from_checkpoint(ckpt: Dict[str, Any]) -> Dict[str, torch.Tensor]
     return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
 
 
+class FreezeSchedule:
+    """When the input preprocessor is trainable (reference: PreprocessorFreezeCallback, src/prepca/callbacks.py; pinned on
+    it by tests/golden/freeze.json): `freeze_epochs` > 0 = frozen at the start of training and released once, at the first
+    epoch >= freeze_epochs; -1 = frozen for good; 0 = never touched."""
+
+    def __init__(self, freeze_epochs: int = 0):
+        self.freeze_epochs = int(freeze_epochs or 0)
+        self.released = False
+
+    def on_train_start(self, model) -> None:
+        if self.freeze_epochs != 0 and hasattr(model, "set_preprocessor_trainable"):
+            model.set_preprocessor_trainable(False)
+
+    def on_epoch_start(self, model, epoch: int) -> bool:
+        """True when this call released the preprocessor."""
+        due = self.freeze_epochs > 0 and epoch >= self.freeze_epochs and not self.released
+        if due and hasattr(model, "set_preprocessor_trainable"):
+            model.set_preprocessor_trainable(True)
+            self.released = True
+            return True
+        return False
+
+
 class Trainer:
     def __init__(self, config: Dict[str, Any], device: Optional[torch.device] = None, verbose: bool = True,
                  sweep: bool = False):
@@ -215,10 +238,8 @@ class Trainer:
         # existed at configure time: a preprocessor unfrozen later becomes trainable for autograd but is only stepped if it
         # already was among the optimizer's parameters.)
         warm = (getattr(module, "config", {}) or {}).get("warmup") or {}
-        self.freeze_epochs = int(warm.get("freeze_epochs", 0) or 0)
-        self._unfrozen = False
-        if self.freeze_epochs != 0 and hasattr(module.model, "set_preprocessor_trainable"):
-            module.model.set_preprocessor_trainable(False)
+        self.freeze = FreezeSchedule(warm.get("freeze_epochs", 0))
+        self.freeze.on_train_start(module.model)
         mon = getattr(module, "monitor_metric", "loss")
         self.monitor = f"val_{mon}"
         self.monitor_mode = "max" if mon == "acc" else "min"
@@ -346,12 +367,8 @@ class Trainer:
         epochs = 1 if self.fast_dev_run else self.max_epochs
         for epoch in range(first_epoch, epochs):
             self.current_epoch = module.current_epoch = epoch
-            if self.freeze_epochs > 0 and epoch >= self.freeze_epochs and not self._unfrozen and \
-                    hasattr(module.model, "set_preprocessor_trainable"):
-                module.model.set_preprocessor_trainable(True)
-                self._unfrozen = True
-                if self.verbose:
-                    print(f"[trainer] epoch {epoch}: input preprocessor unfrozen")
+            if self.freeze.on_epoch_start(module.model, epoch) and self.verbose:
+                print(f"[trainer] epoch {epoch}: input preprocessor unfrozen")
             if hasattr(train_loader, "set_epoch"):
                 train_loader.set_epoch(epoch)
             module.train()
