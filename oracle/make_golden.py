@@ -786,6 +786,50 @@ def make_freeze():
         json.dump(out, f)
     print(f"[freeze] wrote {path}: {out}")
 
+LOADCFG_YAML = """project: demo
+data:
+  file_path: ${VIT_GOLD_ROOT}/train.h5
+  val_path: $VIT_GOLD_ROOT/val.h5
+  extra: ["~/cov.pt", 3, {nested: "${VIT_GOLD_ROOT}/x"}]
+  num_samples: 100
+model:
+  hidden_size: 32
+  name: "plain string"
+train:
+  precision: 'bf16-mixed'
+  grad_clip: 0.5
+"""
+
+
+def make_loadcfg():
+    """`load_config` (src/utils.py:311-359) on a plain experiment YAML: the reference's own function with VIT_GOLD_ROOT and HOME
+    fixed; tests/golden/loadcfg.json holds the YAML text, the environment and the dict it returned (the W&B-export
+    unwrapping of that function is out of scope here and not exercised)."""
+    import json
+    import tempfile
+
+    _import_reference()
+    from src.utils import load_config as ref_load
+
+    env = {"VIT_GOLD_ROOT": "/data/gold", "HOME": "/home/u"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+            f.write(LOADCFG_YAML)
+        got = ref_load(f.name)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        os.unlink(f.name)
+    path = os.path.join(ROOT, "tests", "golden", "loadcfg.json")
+    with open(path, "w") as fo:
+        json.dump({"yaml": LOADCFG_YAML, "env": env, "expected": got}, fo, indent=1)
+    print(f"[loadcfg] wrote {path}: {got['data']}")
+
 
 def main():
     torch.manual_seed(0)
@@ -815,6 +859,7 @@ def main():
     make_names()
     make_config()
     make_freeze()
+    make_loadcfg()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -825,7 +870,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze, "loadcfg": make_loadcfg,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:

@@ -264,3 +264,19 @@ def test_freeze_schedule_matches_reference_callback():
             epoch[0] = ep
             sch.on_epoch_start(m, ep)
         assert calls == want, (fe, calls, want)
+
+
+def test_load_config_matches_reference_function(tmp_path, monkeypatch):
+    """tests/golden/loadcfg.json: the reference's own `load_config` (src/utils.py:311-359) on a plain experiment YAML with the
+    environment fixed: $VAR / ${VAR} / ~ expanded in every string, nested lists and dicts included."""
+    import json
+
+    from vit_amd.utils import load_config
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "loadcfg.json")) as f:
+        doc = json.load(f)
+    for k, v in doc["env"].items():
+        monkeypatch.setenv(k, v)
+    path = tmp_path / "c.yaml"
+    path.write_text(doc["yaml"])
+    assert load_config(str(path)) == doc["expected"]
