@@ -380,7 +380,7 @@ __global__ __launch_bounds__(AW * 64) void attn_bwd_dkv_kernel(AttnArgs p) {
           float mk = 1.f;
           if (p.drop.thr) {
             const unsigned long long row = (unsigned long long)bh * T + (qb0 + j * 16 + lg * 4 + r);
-            const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, row * half_cols + ((unsigned)key >> 1));
+            const unsigned hsh = drop_bits(drop_rowkey(p.drop, row), (unsigned)key >> 1);
             const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
             mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
           }
@@ -876,10 +876,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   char* Oimg = smem + rows_alloc * (DH * 2);
   float* lse_s = (float*)(smem + 2 * rows_alloc * (DH * 2));
   float* del_s = lse_s + rows_alloc;
+  unsigned* rk_s = (unsigned*)(del_s + rows_alloc);  // dropout row keys of the head's query rows
   load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, rows_alloc, tid, blockDim.x);
   for (int i = tid; i < rows_alloc; i += blockDim.x) {
     lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
     del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
+    rk_s[i] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + i) : 0u;
   }
   __syncthreads();
   const int k00 = (part * p.wpw + wave) * RQ * 16;
@@ -903,8 +905,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
     for (int i = 0; i < DH / 16; ++i) dkt[rq][i] = dvt[rq][i] = zero4();
   }
   const float c = p.scale * LOG2E;
-  const unsigned half_cols = (unsigned)((T + 1) >> 1);
-  const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
 
   for (int qt = 0; qt < ntl; ++qt) {
     const int qb0 = qt * RT;
@@ -935,6 +935,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
           }
           const f32x4 l4 = *(const f32x4*)(lse_s + qb0 + j * 16 + lg * 4);
           const f32x4 d4 = *(const f32x4*)(del_s + qb0 + j * 16 + lg * 4);
+          const u32x4 rk4 = *(const u32x4*)(rk_s + qb0 + j * 16 + lg * 4);
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq) {
             const unsigned key = k00 + rq * 16 + l15;
@@ -944,10 +945,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
               const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
               float mk = 1.f;
               if (p.drop.thr) {
-                // pair index = (bh*T + q) * half_cols + key/2, split into a wave-uniform 64-bit base and a small
-                // per-lane 32-bit part (the straightforward 64-bit form cost ~70 VGPRs here)
-                const unsigned idx32 = (unsigned)(qb0 + j * 16 + lg * 4 + r) * half_cols + (key >> 1);
-                const unsigned hsh = drop_hash(p.drop.k0, p.drop.k1, drop_base + idx32);
+                const unsigned hsh = drop_bits(rk4[r], key >> 1);
                 const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
                 mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
               }
@@ -1028,16 +1026,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
 // Two halves of 128 queries keep the dS image at 60 KiB: LDS = 3 x 26 KiB (Q, dO, K) + 58.5 KiB + statistics = 138 KiB at
 // T = 197, one workgroup per CU.  delta = rowsum(dO o (O + O_lo)) is computed up front from global O (loads issued before
 // the staging barrier) and dO from the LDS.
-// Dropout multipliers of 4 consecutive query rows (row0 .. row0+3) at ONE key for the key-owner orientation of the backward
-// kernels.  The mask is defined per (row, key pair): lanes l15 and l15 ^ 1 hold the two keys of a pair and would evaluate
-// the same four hashes; instead the even lane hashes rows 0, 1, the odd lane rows 2, 3, and they trade results across the
-// lane pair (a DPP move each): 2 hashes + 2 moves per 4 elements instead of 4 hashes.
-__device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, unsigned long long base, unsigned half_cols,
-                                                    unsigned row0, unsigned key, int l15, float (&mk)[4]) {
+// Dropout multipliers of 4 consecutive query rows at ONE key for the key-owner orientation of the backward kernels, from
+// the rows' keys `rk` (staged in the LDS once per head).  The mask word belongs to a (row, key pair): lanes l15 and l15 ^ 1
+// hold the two keys of a pair and would evaluate the same four words; instead the even lane evaluates rows 0, 1, the odd
+// lane rows 2, 3, and they trade results across the lane pair by DPP: 2 words + 2 moves per 4 elements instead of 4 words.
+__device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, const u32x4& rk, unsigned key, int l15, float (&mk)[4]) {
   const unsigned odd = (unsigned)l15 & 1u;
-  const unsigned ra = row0 + 2u * odd;
-  const unsigned ha = drop_hash(d.k0, d.k1, base + (ra * half_cols + (key >> 1)));
-  const unsigned hb = drop_hash(d.k0, d.k1, base + ((ra + 1u) * half_cols + (key >> 1)));
+  const unsigned ha = drop_bits(odd ? rk[2] : rk[0], key >> 1);
+  const unsigned hb = drop_bits(odd ? rk[3] : rk[1], key >> 1);
   // lane ^ 1 by DPP quad_perm [1,0,3,2] (one VALU move; __shfl_xor would go through ds_bpermute)
   const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
   const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
@@ -1113,6 +1109,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
   char* dSimg = smem + 3 * R * (DH * 2);
   float* lse_s = (float*)(dSimg + R * DSP);
   float* del_s = lse_s + R;
+  unsigned* rk_s = (unsigned*)(del_s + R);  // dropout row keys of the head's query rows
 
   // ---- loads in flight before the first barrier: this wave's K / V rows, the O (+ residual) chunks of the delta pre-pass
   const int k00 = wave * RQ * 16;
@@ -1149,6 +1146,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
       if (dch == 0) {
         del_s[row] = row < T ? d_ : 0.f;
         lse_s[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
+        rk_s[row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
         if (row < T) p.delta[(long)bh * T + row] = d_;
       }
     }
@@ -1156,8 +1154,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
   __syncthreads();
 
   const float c = p.scale * LOG2E;
-  const unsigned half_cols = (unsigned)((T + 1) >> 1);
-  const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
   const int nq = R >> 4, npairs = (nq + 1) >> 1, nks = (T + 31) >> 5;
   f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16], csq[DPW];
 #pragma unroll
@@ -1200,11 +1196,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
             }
             const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
             const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
+            const u32x4 rk4 = *(const u32x4*)(rk_s + q0 + lg * 4);
 #pragma unroll
             for (int rq = 0; rq < RQ; ++rq) {
               const unsigned key = k00 + rq * 16 + l15;
               float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-              if (p.drop.thr) drop_mask4_keyowner(p.drop, drop_base, half_cols, (unsigned)(q0 + lg * 4), key, l15, mk);
+              if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
@@ -1349,9 +1346,8 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
   char* QD = smem;                      // two buffers of [Q half | dO half]
   char* Kimg = smem + 4 * HALFB;
   char* dSimg = Kimg + R * (DH * 2);
-  float* stats = (float*)(dSimg + R * DSP);  // two sets of [lse | delta], R floats each: heads alternate
+  float* stats = (float*)(dSimg + R * DSP);  // two sets of [lse | delta | dropout row key], R words each: heads alternate
   const float c = p.scale * LOG2E;
-  const unsigned half_cols = (unsigned)((T + 1) >> 1);
   const int k00 = wave * RQ * 16;
   const int dch = lane % CPR;
 
@@ -1410,6 +1406,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
       if (dch == 0 && row < row_hi && row < R) {
         st[R + row] = row < T ? d_ : 0.f;
         st[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;  // (prefetching it with the chunks cost 4 spills: slower)
+        ((unsigned*)st)[2 * R + row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
         if (row < T) p.delta[(long)bh * T + row] = d_;
       }
     }
@@ -1431,10 +1428,10 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
   int u = 0, hidx = 0;
   for (; bh < BH; bh += gridDim.x, ++hidx) {
     const int bh_next = bh + gridDim.x;
-    const float* lse_s = stats + (hidx & 1) * (2 * R);
+    const float* lse_s = stats + (hidx & 1) * (3 * R);
     const float* del_s = lse_s + R;
+    const unsigned* rk_s = (const unsigned*)(del_s + R);
     const int b = bh / p.H, h = bh - b * p.H;
-    const unsigned long long drop_base = (unsigned long long)bh * T * half_cols;
     f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
 #pragma unroll
     for (int i = 0; i < DH / 16; ++i)
@@ -1478,11 +1475,12 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
               }
               const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
               const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
+              const u32x4 rk4 = *(const u32x4*)(rk_s + q0 + lg * 4);
 #pragma unroll
               for (int rq = 0; rq < RQ; ++rq) {
                 const unsigned key = k00 + rq * 16 + l15;
                 float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-                if (p.drop.thr) drop_mask4_keyowner(p.drop, drop_base, half_cols, (unsigned)(q0 + lg * 4), key, l15, mk);
+                if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
@@ -1600,7 +1598,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
           }
         }
       }
-      if (bh_next < BH) delta_finish(bh_next, stats + ((hidx + 1) & 1) * (2 * R), drow_lo, drow_hi);
+      if (bh_next < BH) delta_finish(bh_next, stats + ((hidx + 1) & 1) * (3 * R), drow_lo, drow_hi);
       __syncthreads();  // dS and (after the last half) the K image are free; the next head's statistics are visible
       if (last_half && bh_next < BH) issue_k(bh_next);  // lands during the next head's first phase A
     }
@@ -1609,7 +1607,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 
 static bool persist_fits(int T, int dh) {
   const size_t rows = (T + 15) & ~15;
-  return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 16) <= 160 * 1024;
+  return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24) <= 160 * 1024;
 }
 
 int g_attn_debug = 0;
@@ -1617,7 +1615,7 @@ int g_attn_bwd_fused = 3;  // vit_set_option("attn_bwd_fused"): 0 = two-kernel b
 
 static bool fused_fits(int T, int dh) {
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
-  return T <= 240 && rows * (3 * dhp * 2 + DSP + 8) <= 160 * 1024;
+  return T <= 240 && rows * (3 * dhp * 2 + DSP + 12) <= 160 * 1024;
 }
 
 // resident kernels: a (batch, head)'s whole K/V (or Q/dO) in the LDS -- at head_dim 64 up to T = 592 rows (2 x 74 KiB; the
@@ -1629,7 +1627,7 @@ int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, h
 
 static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + two f32 rows of statistics
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
-  return 2 * rows * dhp * 2 + 2 * rows * 4 <= 160 * 1024;
+  return 2 * rows * dhp * 2 + 3 * rows * 4 <= 160 * 1024;
 }
 
 static void res_geometry(int T, int* nsplit, int* wpw) {
@@ -1679,7 +1677,8 @@ struct Attn32Args {
 
 __device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned long long row, unsigned half_cols, unsigned col) {
   if (!d.thr) return 1.f;
-  const unsigned h = drop_hash(d.k0, d.k1, row * half_cols + (col >> 1));
+  (void)half_cols;
+  const unsigned h = drop_bits(drop_rowkey(d, row), col >> 1);
   const unsigned r16 = (col & 1) ? (h >> 16) : (h & 0xFFFFu);
   return r16 >= d.thr ? d.scale : 0.f;
 }
@@ -1963,14 +1962,14 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.dbg = g_attn_debug;
   if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
     const size_t rows = (T + 15) & ~15;
-    const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 8);
+    const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 12);
     if (g_attn_bwd_fused == 3 && persist_fits(T, dh)) {
       static bool attr = false;
       if (!attr) {
         VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
       }
-      const size_t sm = 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 16);
+      const size_t sm = 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24);
       hipLaunchKernelGGL(attn_bwd_persist_kernel, dim3(std::min(B * H, 256)), dim3(512), sm, st, a);
       VIT_LAUNCH_CHECK();
       return VIT_OK;
@@ -1995,7 +1994,7 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
-    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 2 * (size_t)((T + 15) & ~15) * 4), st, rc);
+    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 3 * (size_t)((T + 15) & ~15) * 4), st, rc);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);

@@ -54,16 +54,23 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
 }
 
 // ---- dropout: counter-based, stateless, identical in every kernel that needs the same mask -----------
-// One 32-bit hash per PAIR of adjacent columns: element (row, col) of a [rows, ncols] tensor (ncols even) draws
-// the low (col even) or high (col odd) 16 bits of hash(row * ncols/2 + col/2).  keep <=> r16 >= thr,
-// thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr) so the mask is exactly unbiased.
+// Two levels.  Every ROW of a [rows, ncols] tensor has a 32-bit key, a full-strength hash of (seed keys, 64-bit row index):
+// drop_rowkey.  Inside the row, one 32-bit word per PAIR of adjacent columns, drop_bits(rowkey, col / 2): element (row, col)
+// draws its low (col even) or high (col odd) 16 bits.  keep <=> r16 >= thr, thr = round(p * 65536); kept values are scaled
+// by 65536 / (65536 - thr) so the mask is exactly unbiased.  The row key costs ~10 integer ops and is amortised over the
+// row (kernels keep it in a register or stage it in the LDS); the per-pair word is 7 ops (xor, 2 x multiply-xorshift) --
+// the softmax / epilogue kernels are VALU-bound and the single-level hash of (row * ncols/2 + col/2) cost 14 per pair with
+// its 64-bit index arithmetic.  One multiply-xorshift round per pair is NOT enough: adjacent pairs correlate at 0.07.
 // The reference's own masks come from torch's Philox stream and are implementation-defined (they differ between
 // its CPU and CUDA runs too), so only the distribution is part of the contract.
-__device__ __forceinline__ unsigned drop_hash(unsigned k0, unsigned k1, unsigned long long pair_idx) {
-  // one round of the "lowbias32" integer finaliser (xorshift-multiply x2) keyed on both ends: 8 integer ops per PAIR of
-  // elements -- the fused GEMM epilogues are VALU-bound, so the mask generator has to be this cheap
-  unsigned x = (unsigned)pair_idx ^ k0 ^ ((unsigned)(pair_idx >> 32) * 0x9E3779B9u);
+__device__ __forceinline__ unsigned drop_hash(unsigned k0, unsigned k1, unsigned long long idx) {
+  unsigned x = (unsigned)idx ^ k0 ^ ((unsigned)(idx >> 32) * 0x9E3779B9u);
   x ^= x >> 16; x *= 0x7feb352du; x += k1; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned drop_bits(unsigned rowkey, unsigned colpair) {
+  unsigned x = (colpair ^ rowkey) * 0x2C1B3C6Du;
+  x ^= x >> 15; x *= 0x297A2D39u; x ^= x >> 16;
   return x;
 }
 struct DropCfg {
@@ -95,10 +102,13 @@ __host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint64_t si
   d.dyn = nullptr;
   return d;
 }
-// multiplier (0 or scale) for 2 adjacent columns starting at even column `col`
+__device__ __forceinline__ unsigned drop_rowkey(const DropCfg& d, unsigned long long row) { return drop_hash(d.k0, d.k1, row); }
+// multiplier (0 or scale) for 2 adjacent columns starting at even column `col` (`half_cols` is no longer part of the hash;
+// the parameter stays for the call sites' sake).  `row` is loop-invariant at most call sites: the compiler hoists its key.
 __device__ __forceinline__ void drop_pair(const DropCfg& d, unsigned long long row, unsigned half_cols, unsigned col,
                                           float& m0, float& m1) {
-  unsigned h = drop_hash(d.k0, d.k1, row * half_cols + (col >> 1));
+  (void)half_cols;
+  const unsigned h = drop_bits(drop_rowkey(d, row), col >> 1);
   m0 = ((h & 0xFFFFu) >= d.thr) ? d.scale : 0.f;
   m1 = ((h >> 16) >= d.thr) ? d.scale : 0.f;
 }
