@@ -57,7 +57,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "attn_bwd_fused": attention backward form: 3 (default) = the persistent pipelined single kernel where it fits (head_dim 64,
  *                T <= 224), else as 1; 1 / 2 = the fused single kernel with 8 / 16 waves (T <= 240); 0 = the dQ + dK/dV pair.
  *   "attn_debug": timing diagnostics for the fused kernels (bit 1 = no phase B, 2 = no phase A, 4 = no operand staging, 8 = no
- *                dK/dV stores); results are meaningless while it is non-zero.
+ *                dK/dV stores, 16 / 32 (persistent form) = no K/V-row and delta-chunk loads / no lse loads and delta stores);
+ *                results are meaningless while it is non-zero.  (Skipping phase A exposes the store-completion part of the
+ *                s_waitcnt vmcnt(0) in front of the barriers, so the remainder over-states the non-compute time.)
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.
  *   "attn_res_max_t": longest sequence the resident attention kernels take (default 592 = what fits the LDS at head_dim
  *                64); longer ones, or everything with 0, go to the tiled kernels.

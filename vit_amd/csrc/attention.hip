@@ -1366,6 +1366,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
     if (!(p.dbg & 4)) dma_rows64(Kimg, p.qkv + qoff_of(bh) + HD, ld, 0, R, T, wave, lane);
   };
   auto issue_regs = [&](int bh) {  // this wave's K / V rows of head bh
+    if (p.dbg & 16) return;
     const short* kb_ = p.qkv + qoff_of(bh) + HD;
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) {
@@ -1385,7 +1386,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
       o4[i] = d4[i] = l4[i] = (i32x4){0, 0, 0, 0};
-      if (row < T && row < row_hi) {
+      if (row < T && row < row_hi && !(p.dbg & 16)) {
         const long e0 = co + (long)row * ldc + dch * 8;
         o4[i] = *(const i32x4*)(p.ctx + e0);
         d4[i] = *(const i32x4*)(p.dctx + e0);
@@ -1394,6 +1395,14 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
     }
   };
   auto delta_finish = [&](int bh, float* st, int row_lo, int row_hi) {
+    // lse of the two rows first: issued while the chunk loads are still in flight, not after the reduction (that was one
+    // more exposed round trip per unit)
+    float lsev[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
+      lsev[i] = (row < T && row < row_hi && !(p.dbg & 32)) ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
@@ -1405,9 +1414,9 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
       d_ = sum_lanes_cpr<CPR>(d_);
       if (dch == 0 && row < row_hi && row < R) {
         st[R + row] = row < T ? d_ : 0.f;
-        st[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;  // (prefetching it with the chunks cost 4 spills: slower)
+        st[row] = lsev[i];
         ((unsigned*)st)[2 * R + row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
-        if (row < T) p.delta[(long)bh * T + row] = d_;
+        if (row < T && !(p.dbg & 32)) p.delta[(long)bh * T + row] = d_;
       }
     }
   };
@@ -1437,7 +1446,8 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
     for (int i = 0; i < DH / 16; ++i)
 #pragma unroll
       for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
-    float* csum = p.csum_part ? p.csum_part + ((long)b * NW + wave) * ld + h * DH : nullptr;
+    // two partial rows per wave (one per half of the queries): no read-modify-write of a partial through global memory
+    float* csum = p.csum_part ? p.csum_part + ((long)b * NW + wave) * 2 * ld + h * DH : nullptr;
     for (int half = 0; half < nhalves; ++half, ++u) {
       char* cur = QD + (u & 1) * (2 * HALFB);
       char* nxt = QD + ((u + 1) & 1) * (2 * HALFB);
@@ -1553,13 +1563,9 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
           u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           if (have && q < T) *(u32x2*)(o + dt * 16 + lg * 4) = pk;
           else pk = (u32x2){0u, 0u};
-          if (csum) {  // this wave's dQ column sums: first half writes its partial row, the second adds to it
-            f32x4 t = rows16_sum(bf_round4(pk));
-            float* dst = csum + dt * 16 + lg * 4;
-            if (l15 == 0) {
-              if (half) t += *(const f32x4*)dst;
-              *(f32x4*)dst = t;
-            }
+          if (csum) {  // this wave's dQ column sums of this half: partial row `half`
+            const f32x4 t = rows16_sum(bf_round4(pk));
+            if (l15 == 0) *(f32x4*)(csum + half * ld + dt * 16 + lg * 4) = t;
           }
         }
       }
@@ -1586,7 +1592,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
             }
           }
         }
-        if (csum) {
+        if (csum) {  // key / value thirds: row 0 carries the sums, row 1 zeros (and a zero query third when there is one half)
 #pragma unroll
           for (int dt = 0; dt < DH / 16; ++dt) {
             const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
@@ -1594,6 +1600,9 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
             if (l15 == 0) {
               *(f32x4*)(csum + HD + d) = tk;
               *(f32x4*)(csum + 2 * HD + d) = tv;
+              *(f32x4*)(csum + ld + HD + d) = zero4();
+              *(f32x4*)(csum + ld + 2 * HD + d) = zero4();
+              if (nhalves == 1) *(f32x4*)(csum + ld + d) = zero4();
             }
           }
         }
@@ -1625,6 +1634,7 @@ constexpr int RES_MAX_T = 592, RES_MAX_DH = 64, RES_RQ = 2;
 int g_attn_res_max_t = RES_MAX_T;  // vit_set_option("attn_res_max_t"): larger T goes to the tiled kernels
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
 
+static bool persist_fits(int T, int dh);
 static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + two f32 rows of statistics
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
   return 2 * rows * dhp * 2 + 3 * rows * 4 <= 160 * 1024;
@@ -1919,8 +1929,10 @@ int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const v
     res_geometry(T, &nsplit, &wpw);
     size_t wsb = 0;
     float* part = (float*)ctx_workspace(h, &wsb);
-    const bool fused = g_attn_bwd_fused && fused_fits(T, dh);  // one partial row per wave: 8 waves per (batch) there
-    const int prow = fused ? B * (g_attn_bwd_fused == 2 ? 16 : 8) : B * nsplit * wpw;
+    const bool fused = g_attn_bwd_fused && fused_fits(T, dh);  // partial rows per batch: one per wave (8 / 16 waves), or in
+    // the persistent form two per wave (one per half of the queries)
+    const bool persist = g_attn_bwd_fused == 3 && persist_fits(T, dh);
+    const int prow = fused ? B * (persist || g_attn_bwd_fused == 2 ? 16 : 8) : B * nsplit * wpw;
     if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
       // the resident kernels leave one partial row per wave: column sums of what they stored
       int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed,
