@@ -154,6 +154,9 @@ def main():
     from vit_amd.trainer import Trainer, seed_everything
 
     rank, local, world = ddp_mod.init_distributed()
+    # exchanging: N > 1, or VIT_DIST_SINGLE=1 (one rank, but the process group exists and every collective of the step runs:
+    # the RCCL rehearsal a one-GPU box allows)
+    exchanging = ddp_mod.exchange_active()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if os.environ.get("VIT_BENCH_SHARE_GPU"):  # rehearsal: all ranks on device 0 (use with VIT_DIST_BACKEND=gloo)
@@ -177,7 +180,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
         module = ViTLModule(config=config)
-    use_graph = world == 1 and args.graph and not args.no_graph
+    use_graph = not exchanging and args.graph and not args.no_graph
     config["train"]["hip_graph"] = use_graph
     trainer = Trainer(config["train"], device=dev, verbose=False)
     trainer._setup(module)
@@ -212,7 +215,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if exchanging:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -257,7 +260,7 @@ def main():
         dt_inst = time.perf_counter() - t1
         timing_on[0] = False
         module.model.engine.overlap_dw = overlap_was
-    if world > 1:
+    if exchanging:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -267,7 +270,7 @@ def main():
     # apart, which no longer matters: `value` is already taken), (b) the bare all-reduce of the flat gradient buffer in
     # the step's own buckets with nothing else on the GPU -> algorithm / bus bandwidth over xGMI.
     comm = None
-    if world > 1:
+    if exchanging:
         dist = torch.distributed
         eng = module.model.engine
         red = trainer.reducer
@@ -328,7 +331,7 @@ def main():
         }
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not exchanging and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args.workload, L, P, D, layers, heads)
 
     if rank == 0:
@@ -347,7 +350,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "comm": comm, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchanging:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

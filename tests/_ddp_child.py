@@ -53,7 +53,7 @@ def main(out_dir, precision, exchange):
                 "mode": trainer.reducer.mode if trainer.reducer else None,
                 "grad_norm": float(trainer.optimizer.last_grad_norm.sqrt())},
                os.path.join(out_dir, f"rank{trainer.rank}.pt"))
-    if trainer.world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

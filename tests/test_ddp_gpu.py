@@ -14,18 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = os.path.join(ROOT, "tests", "_ddp_child.py")
 
 
-def _run(tmp_path, world, precision, exchange):
+def _run(tmp_path, world, precision, exchange, single_env=None):
     from vit_amd.launch import launch_ranks
 
-    out = tmp_path / f"w{world}_{precision}_{exchange}"
+    out = tmp_path / f"w{world}_{precision}_{exchange}_{'rccl' if single_env else 'plain'}"
     out.mkdir()
     env = {"VIT_DIST_BACKEND": "gloo"}
     if world == 1:
         import subprocess
 
         e = dict(os.environ)
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VIT_DIST_SINGLE", "VIT_DIST_BACKEND"):
             e.pop(k, None)
+        e.update(single_env or {})
         r = subprocess.run([sys.executable, CHILD, str(out), precision, exchange], env=e, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -69,3 +70,27 @@ def test_zero1_exchange_matches_allreduce(tmp_path):
     n = a[0]["n_trainable"]
     assert abs(a[0]["grad_norm"] - z[0]["grad_norm"]) <= 1e-6 * a[0]["grad_norm"]
     assert torch.equal(a[0]["params"][:n], z[0]["params"][:n])
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "zero1"])
+def test_rccl_single_rank_rehearsal(tmp_path, exchange):
+    """RCCL itself on the one GPU of the box: VIT_DIST_SINGLE=1 creates a 1-rank "nccl" process group and the step runs
+    every collective it runs at N > 1 -- parameter broadcast, the per-bucket asynchronous all-reduce (AVG) or in-place
+    reduce-scatter, the shard-norm all-reduce and the in-place all-gather of 'zero1' -- on RCCL's stream, ordered against
+    the engine's two HIP streams.  With one rank every collective is the identity, so the step must leave exactly the
+    parameters of the run without a process group."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    plain = _run(tmp_path, 1, "bf16-mixed", exchange)[0]
+    rccl = _run(tmp_path, 1, "bf16-mixed", exchange,
+                single_env={"VIT_DIST_SINGLE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                            "HSA_ENABLE_IPC_MODE_LEGACY": "0"})[0]
+    assert plain["backend"] is None and plain["mode"] is None
+    assert rccl["backend"] == "nccl" and rccl["mode"] == exchange and rccl["world"] == 1
+    n = plain["n_trainable"]
+    assert torch.equal(plain["grads"][:n], rccl["grads"][:n])
+    assert plain["grad_norm"] == rccl["grad_norm"]
+    assert torch.equal(plain["params"], rccl["params"])

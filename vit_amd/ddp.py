@@ -18,7 +18,24 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["GradAllReducer", "ShardedGradReducer", "make_reducer", "broadcast_parameters", "init_distributed",
-           "shard_indices"]
+           "shard_indices", "exchange_active"]
+
+
+def _single_rank_rehearsal() -> bool:
+    """VIT_DIST_SINGLE=1: create the process group and run every collective of the step although WORLD_SIZE is 1.
+    A one-GPU box cannot host two RCCL ranks (RCCL refuses duplicate devices), so this is how the RCCL calls themselves --
+    in-place reduce-scatter / all-gather slices, async work handles, stream ordering against the second HIP stream -- are
+    executed there (tests/test_ddp_gpu.py); the averaged values are trivially the rank's own."""
+    import os
+
+    return os.environ.get("VIT_DIST_SINGLE", "") not in ("", "0")
+
+
+def exchange_active(group=None) -> bool:
+    """True when the step has a gradient exchange to run: more than one rank, or the single-rank rehearsal."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or _single_rank_rehearsal()
 
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -28,7 +45,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_rehearsal()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -44,7 +61,7 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 def broadcast_parameters(flat: torch.Tensor, src: int = 0, group=None):
     """DDP start-up semantics: every replica begins from rank 0's parameters."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if exchange_active(group):
         dist.broadcast(flat, src=src, group=group)
 
 
@@ -70,6 +87,7 @@ class GradAllReducer:
         self.buckets = buckets
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = exchange_active(group)
         self.max_bucket_elems = max_bucket_elems
         self._pending = []
         self._seen = 0
@@ -81,7 +99,7 @@ class GradAllReducer:
 
     def bucket_ready(self, lo: int, hi: int):
         """Engine callback (called on the host right after the kernels that complete grads[lo:hi] were enqueued)."""
-        if self.world <= 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         g = self._get()
         # an all-reduce bigger than max_bucket_elems is split so that the first pieces are on the wire early
@@ -135,10 +153,10 @@ class ShardedGradReducer(GradAllReducer):
         return lo + self.rank * c, lo + (self.rank + 1) * c
 
     def is_sharded(self, lo: int, hi: int) -> bool:
-        return self.world > 1 and self.sharded[self.buckets.index((lo, hi))]
+        return self.active and self.sharded[self.buckets.index((lo, hi))]
 
     def bucket_ready(self, lo: int, hi: int):
-        if self.world <= 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if not self.is_sharded(lo, hi) or dist.get_backend(self.group) != "nccl":
             return super().bucket_ready(lo, hi)
@@ -150,7 +168,7 @@ class ShardedGradReducer(GradAllReducer):
 
     def all_gather_params(self, flat: torch.Tensor):
         """After the sharded update: every rank receives the other ranks' updated slices of the sharded buckets."""
-        if self.world <= 1:
+        if not self.active:
             return
         works = []
         for (lo, hi), sh in zip(self.buckets, self.sharded):

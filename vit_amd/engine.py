@@ -450,6 +450,19 @@ class ViTEngine:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.side_stream)
             self._side_reads.clear()
 
+    def _notify(self, lo: int, hi: int):
+        """Hand grads[lo:hi] to the gradient exchange.  With the second stream on, the collective is enqueued from THAT stream
+        (after it has caught up with the main stream's position): the exchange then waits for the weight-gradient GEMMs
+        without the main stream having to join them, and the data path of the next layer keeps running."""
+        cb = self.grad_ready_cb
+        if cb is None:
+            return
+        if self.side_stream is None:
+            return cb(lo, hi)
+        self.side_stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.side_stream):
+            cb(lo, hi)
+
     def _setup_side(self):
         from . import _cabi
 
@@ -483,7 +496,6 @@ class ViTEngine:
         Mp = self._Mp
         scale = dh ** -0.5
         rope = self._rope_tables(T) if c.pos_encoding_type == "rope" else None
-        cb = self.grad_ready_cb
         hn = self.layout.head
         dloss = dloss.reshape(1).to(torch.float32).contiguous()
 
@@ -502,8 +514,7 @@ class ViTEngine:
             vf.layernorm_bwd_fused(t["dlast"].view(M, D), a["x"][L].view(M, D), self.p("vit.layernorm.weight"), a["meanF"],
                                    a["rstdF"], None, dx, self.g("vit.layernorm.weight"), self.g("vit.layernorm.bias"),
                                    t["dy"], self.g(last_pre + "output.dense.bias"), (ph, seed, self._site(L - 1, 2)))
-        if cb:
-            cb(self.layout.tail_start, self.layout.n_trainable)
+        self._notify(self.layout.tail_start, self.layout.n_trainable)
         for i in reversed(range(L)):
             pre = f"vit.encoder.layer.{i}."
             # x2 = dropout(g W2^T + b2) + x1      (t["dy"] = mask * dx and db2 were produced by the LN backward above)
@@ -538,8 +549,6 @@ class ViTEngine:
             self._dw(t["dqkv"], a["h1"][i], M=3 * D, N=D, K=Mp, a_trans=True, b_trans=True, out=self._qkv_wgrad(i),
                      split_k=-1, reads=("dqkv",))
             vf.gemm(t["dqkv"], self._qkv16(i), M=Mp, N=D, K=3 * D, b_trans=True, out=t["dh"])
-            if cb:
-                self._join_side()  # data parallel: the layer's bucket is handed to the exchange below, complete
             self._before_write("dy")  # the LayerNorm backward below rewrites t["dy"] (read by this layer's FC2 weight gradient)
             if i > 0:
                 # LN1 backward -> dx (input of this layer = output of layer i-1), plus layer i-1's FC2 pieces
@@ -553,8 +562,7 @@ class ViTEngine:
                                  a["rstd1"][i], dres=dx, dx=dx_other, dgamma=self.g(pre + "layernorm_before.weight"),
                                  dbeta=self.g(pre + "layernorm_before.bias"))
             dx, dx_other = dx_other, dx
-            if cb:
-                cb(*self.layout.layer_ranges[i])
+            self._notify(*self.layout.layer_ranges[i])
         e = "vit.embeddings."
         dpos = self.g(e + "position_embeddings").view(T, D) if c.pos_encoding_type == "learned" else None
         vf.embed_finish_bwd(dx.view(B, T, D), self.g(e + "cls_token").view(D), dpos, dropout=(ph, seed, 0),
@@ -563,8 +571,7 @@ class ViTEngine:
         vf.gemm(t["dpatch"], a["patches"], M=D, N=P, K=B * N, a_trans=True, b_trans=True,
                 out=self.g(e + "patch_embeddings.projection.weight").view(D, P), split_k=-1)
         self._join_side()
-        if cb:
-            cb(self.layout.embed_start, self.layout.embed_end)
+        self._notify(self.layout.embed_start, self.layout.embed_end)
         if need_dx:
             # gradient wrt the signal itself (a trainable input preprocessor sits in front): dpatches = dpatch Wp, then the
             # overlap-add that undoes the tokenizer's unfold

@@ -165,7 +165,8 @@ class Trainer:
         self.acc, self.device0 = select_accelerator_and_devices(config.get("gpus"))
         self.strategy = get_training_strategy(self.world)
         self.device = device or torch.device("cuda", self.local_rank)
-        self.backend = torch.distributed.get_backend() if self.world > 1 else None
+        self.exchanging = ddp_mod.exchange_active()  # world > 1, or the single-rank RCCL rehearsal (VIT_DIST_SINGLE)
+        self.backend = torch.distributed.get_backend() if self.exchanging else None
         self.exchange = str(config.get("ddp_exchange", os.environ.get("VIT_DDP_EXCHANGE", "allreduce")))
         # train.hip_graph: replay the optimisation step as one captured hipGraph (vit_amd/graph.py; single GPU only)
         self.use_graph = bool(config.get("hip_graph", False))
@@ -224,7 +225,7 @@ class Trainer:
         self.optimizers = [self.optimizer]
         eng = module.model.engine
         self.reducer = None
-        if self.world > 1:
+        if self.exchanging:
             eng._ensure_device_state()
             ddp_mod.broadcast_parameters(eng.flat)
             eng._shadow_version = -1
@@ -251,7 +252,7 @@ class Trainer:
     def training_step(self, module, batch, batch_idx):
         """zero_grad -> forward -> backward (+ overlapped gradient exchange) -> clip -> optimizer step."""
         self._cur_bs = _batch_size(batch)
-        if self.use_graph and self.world == 1:
+        if self.use_graph and not self.exchanging:
             return self._graph_step(module, batch)
         self.optimizer.zero_grad(set_to_none=True)
         loss = module.training_step(batch, batch_idx)
