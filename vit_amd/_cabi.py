@@ -8,7 +8,8 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvit_amd.so")
+# VIT_AMD_LIB: another build of the same library (the diagnostic twin of `python -m vit_amd.build --diag`, tools/pp_diag.py)
+LIB_PATH = os.environ.get("VIT_AMD_LIB") or os.path.join(_HERE, "lib", "libvit_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vit_amd.h")
 
 VIT_OK = 0

@@ -47,7 +47,13 @@ def _torch_libdir() -> str:
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, diag: bool = False, stamps: int = 0, defs=(), tag: str = "") -> str:
+    """`diag=True` builds the DIAGNOSTIC twin libvit_amd_diag.so (-DVIT_PP_DIAG: the ping-pong GEMM can switch off its
+    operand DMA / fragment reads / MFMAs / epilogue for timing, tools/pp_diag.py); it is loaded only when VIT_AMD_LIB names
+    it and is never what the package or the tests use."""
+    tag = ("_" + tag) if tag else (f"_stamp{stamps}" if stamps else ("_diag" if diag else ""))
+    OBJ = os.path.join(CSRC, "_build" + tag)
+    LIB = os.path.join(LIBDIR, f"libvit_amd{tag}.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
@@ -57,6 +63,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-comment", "-DNDEBUG"]
+    if stamps:  # in-kernel s_memtime stamps in the ping-pong GEMM (1 = per segment, 2 = also inside the LOAD segment)
+        flags.append(f"-DVIT_PP_STAMP={int(stamps)}")
+    elif diag:
+        flags.append("-DVIT_PP_DIAG")
+    flags.extend(defs)  # experiment builds: --defs "-DX -DY=1" --tag name -> libvit_amd_name.so
 
     def cc(src):
         obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", ".o"))
@@ -82,4 +93,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, diag="--diag" in sys.argv,
+          stamps=int(sys.argv[sys.argv.index("--stamps") + 1]) if "--stamps" in sys.argv else 0,
+          defs=sys.argv[sys.argv.index("--defs") + 1].split() if "--defs" in sys.argv else (),
+          tag=sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "")

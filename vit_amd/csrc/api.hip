@@ -14,7 +14,7 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2, g_krot;  // gemm2.hip
+extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
 extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_debug;  // attention.hip
 
 static thread_local char g_err[512] = "";
@@ -99,10 +99,6 @@ int vit_set_option(const char* name, int value) {
     vit::g_half_tail = value;
     return VIT_OK;
   }
-  if (strcmp(name, "gemm_krot") == 0) {
-    vit::g_krot = value;
-    return VIT_OK;
-  }
   if (strcmp(name, "gemm_ngroups") == 0) {
     vit::g_grp2 = value;
     return VIT_OK;
@@ -112,7 +108,7 @@ int vit_set_option(const char* name, int value) {
     return VIT_OK;
   }
   if (strcmp(name, "gemm_pp_slots") == 0) {
-    if (value != 8 && value != 10) return VIT_ERR_ARG;
+    if (value != 8) return VIT_ERR_ARG;  // the 10-slot ring (measured 0-15 % slower) was removed with the r02 loop rewrite
     vit::g_pp_slots = value;
     return VIT_OK;
   }
@@ -140,3 +136,13 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes) {
 }
 
 }  // extern "C"
+
+#ifdef VIT_PP_STAMP
+// diagnostic build only (python -m vit_amd.build --stamps N): where gemm3_kernel's workgroup `block` spends its cycles
+namespace vit { extern unsigned long long* g_pp_stamps; extern int g_pp_stamp_block; }
+extern "C" int vit_debug_pp_stamps(void* device_buf_64x_u64, int block) {
+  vit::g_pp_stamps = (unsigned long long*)device_buf_64x_u64;
+  vit::g_pp_stamp_block = block;
+  return 0;
+}
+#endif

@@ -50,8 +50,11 @@ struct Gemm2Args {
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
   int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
   int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
-  int krot;  // ping-pong kernel: K-walk rotation step per tile (0 = every tile starts at K-tile 0); see cursor_next
   int grp2;  // ping-pong kernel: XCDs 0-3 walk the lower half of the N-tiles, XCDs 4-7 the upper half (see tile_coords)
+#ifdef VIT_PP_STAMP
+  unsigned long long* stamps;  // diagnostic build: [8 waves][8] summed s_memtime deltas of workgroup `stamp_block`
+  int stamp_block;
+#endif
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
@@ -593,44 +596,49 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     tm = t / p.tiles_n;
     tn = t - tm * p.tiles_n;
   };
-  // global bases (A, B) of K-tile kt of output tile (tm, tn)
-  auto base_of = [&](int tm, int tn, int kt, const char*& ab, const char*& bb) {
-    const int k0 = k_begin + kt * BK;
-    ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
-    bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
+  // The K-tile stream cursor: global bases (A, B) of the next K-tile to stage.  Everything on this path is SCALAR code that
+  // sits in a LOAD segment, in front of the barrier the other wave group's MFMA segment ends on, and a wave issues one
+  // instruction per ~4-5 cycles: in-kernel stamps (tools/pp_stamps.py) showed the per-K-tile bookkeeping -- bases recomputed
+  // with 64-bit multiplies, ring-slot arithmetic, three branches per phase -- costing as much as the 16 MFMAs it hides
+  // behind.  So: inside an output tile the bases advance by a constant (two 64-bit adds); past the end of the walk the
+  // cursor stays on the last K-tile (its re-fetches land in ring slots nobody reads again: no "is there a next K-tile"
+  // branch in any phase); the ring-slot offsets are one XOR / one masked add per K-tile or phase.
+  const long dA = (A_T == 0) ? (long)BK * 2 : (long)BK * p.lda * 2;  // bytes from one K-tile to the next
+  const long dB = (B_T == 0) ? (long)BK * 2 : (long)BK * p.ldb * 2;
+  int cj = 0, ckt = 0;
+  const char *ca, *cb;
+  auto tile_bases = [&](int j) {
+    int tm, tn;
+    tile_coords(j, tm, tn);
+    ca = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k_begin) * 2 : p.A + ((long)k_begin * p.lda + (long)tm * BM) * 2;
+    cb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k_begin) * 2 : p.B + ((long)k_begin * p.ldb + (long)tn * BN) * 2;
   };
-  // K rotation (p.krot): the workgroups that share an operand panel (same tm: the A panel; same tn: the B panel) run in
-  // lock step, so every line of the panel is requested by all of them within one miss latency and the requests that find
-  // the line pending go to the fabric again (PMC: FC1 reads 376 MB against an 82 MB operand set at a 68 % L2 hit rate).
-  // Starting each tile's K walk at a different K-tile, (tm + tn) * krot mod nk, spreads the sharers over the panel: one
-  // of them misses a line, the others find it cached later.  The sum order of a tile changes with its coordinates -- still a
-  // fixed function of the problem, so results stay run-to-run deterministic.
-  auto rot_of = [&](int tm, int tn) -> int {
-    if (!p.krot) return 0;
-    const int r = ((tm + tn) * p.krot) % nk;
-    return r;
-  };
-  // walking cursor over this workgroup's flat (output tile, K-tile) sequence: no division in the loop
-  int cj = 0, ckt = 0, ctm, ctn, crot;
-  tile_coords(0, ctm, ctn);
-  crot = rot_of(ctm, ctn);
+  tile_bases(0);
   auto cursor_next = [&](const char*& ab, const char*& bb) {  // bases of the cursor's K-tile, then advance
-    int kk = ckt + crot;
-    if (kk >= nk) kk -= nk;
-    base_of(ctm, ctn, kk, ab, bb);
+    ab = ca;
+    bb = cb;
     if (++ckt == nk) {
-      ckt = 0;
-      if (++cj < my_tiles) {
-        tile_coords(cj, ctm, ctn);
-        crot = rot_of(ctm, ctn);
+      if (cj + 1 < my_tiles) {
+        ++cj;
+        ckt = 0;
+        tile_bases(cj);
+      } else {
+        ckt = nk - 1;  // end of the walk: stay
       }
+    } else {
+      ca += dA;
+      cb += dB;
     }
   };
   // one half-tile = 2 LDS-DMA instructions per thread; destination: slot + round*8 KiB + wave*1 KiB (+ lane*16)
-  int islot = 0;  // slot of the next stream index to issue (stream order: A0 B0 B1 A1 per K-tile)
+  static_assert(NSLOT == 8, "the ring arithmetic below is for 8 slots (two K-tiles of four half-tiles)");
+  unsigned dofs = 0;  // byte offset of the slot the next stream index goes to (stream order: A0 B0 B1 A1 per K-tile)
   auto issue_half = [&](const char* base, long half_off, const int (&off)[2]) {
-    char* dst = smem + islot * HALF + wave * 1024;
-    islot = (islot + 1 == NSLOT) ? 0 : islot + 1;
+    char* dst = smem + dofs + wave * 1024;
+    dofs = (dofs + HALF) & (NSLOT * HALF - 1);
+#ifdef VIT_PP_DIAG  // diagnostic build only (tools/pp_diag.py): 16 = no operand DMA, 32 = no fragment reads, 64 = no MFMAs, 128 = no epilogue
+    if (p.debug & 16) return;
+#endif
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
   };
@@ -642,6 +650,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) kc_off[s] = l15 * 128 + (((s * 4 + lg) ^ (l15 >> 1)) << 4);
   auto read_frag = [&](const char* img, int trans, int base16, int s) -> bf16x8 {
+#ifdef VIT_PP_DIAG
+    if (p.debug & 32) return (bf16x8){(short)base16, (short)s, 0, 0, 0, 0, 0, 0};
+#endif
     if (!trans) {
       return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off[s]);
     } else {
@@ -659,6 +670,63 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], b0[2][2], b1[2][2];
 
+// In-kernel stamps (diagnostic build -DVIT_PP_STAMP=1|2 only; tools/pp_stamps.py): where a barrier interval goes.
+//   slot 0 fragment reads issued AND landed   1 LDS-DMA issue   2 counted vmcnt wait   (level 1: all three in slot 2)
+//   slot 3 barrier that ends the LOAD segment + lgkmcnt   4 MFMA segment (issue)   5 closing barrier   6 epilogue + re-align
+#ifdef VIT_PP_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
+#define PP_STX(K)                                                                                \
+  {                                                                                              \
+    unsigned long long t_;                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    st_[K] += t_ - tprev_;                                                                       \
+    tprev_ = t_;                                                                                 \
+  }
+#define PP_CNT st_[7] += 1;
+#if VIT_PP_STAMP == 4
+// level 4: slots 0-3 = the whole LOAD segment of phases P1..P4 (P1 includes the loop tail), 4 = barrier + lgkmcnt,
+// 5 = MFMA segment, 6 = closing barrier + epilogue
+#define PP_ST(K) PP_STX(((K) == 3 ? 4 : (K) == 4 ? 5 : 6))
+#define PP_ST2(K)
+#define PP_ST3(PH)
+#define PP_STL(PH) PP_STX(PH)
+#elif VIT_PP_STAMP == 3
+// level 3: slots 0-3 = "fragment reads landed" of phases P1..P4, 4 = rest of the LOAD segment, 5 = barrier + lgkmcnt,
+// 6 = MFMA segment + closing barrier + epilogue
+#define PP_ST(K) PP_STX(((K) == 2 ? 4 : (K) == 3 ? 5 : 6))
+#define PP_ST2(K)
+#define PP_ST3(PH) PP_STX(PH)
+#define PP_STL(PH) PP_ST(2)
+#else
+#define PP_ST(K) PP_STX(K)
+#define PP_ST3(PH)
+#define PP_STL(PH) PP_ST(2)
+#if VIT_PP_STAMP >= 2
+#define PP_ST2(K) PP_STX(K)
+#else
+#define PP_ST2(K)
+#endif
+#endif
+#else
+#define PP_ST(K)
+#define PP_ST2(K)
+#define PP_ST3(PH)
+#define PP_STL(PH)
+#define PP_CNT
+#endif
+#ifdef VIT_PP_NOPRIO
+#define PP_SETPRIO1
+#else
+#define PP_SETPRIO1 __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef VIT_PP_DIAG
+#define PP_DO_MFMA (!(p.debug & 64))
+#else
+#define PP_DO_MFMA true
+#endif
 #define PP_READ_A(IMG)                                                                           \
   _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) \
       af[i_][s_] = read_frag(IMG, A_T, wr * 64 + i_ * 16, s_);
@@ -671,39 +739,56 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   __builtin_amdgcn_s_barrier();                                                                  \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  __builtin_amdgcn_s_setprio(1);                                                                 \
+  PP_ST(3)                                                                                       \
+  PP_SETPRIO1                                                                 \
+  if (PP_DO_MFMA)                                                                                \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
       _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
           acc[HA * 4 + i_][HB * 2 + j_] =                                                        \
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j_][s_], af[i_][s_], acc[HA * 4 + i_][HB * 2 + j_], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  __builtin_amdgcn_s_barrier();
-// stage one half-tile of K-tile IT (if it exists) and leave four half-tiles in flight; `relaxed`: the epilogue's stores
-// were issued after the three older half-tiles still in flight -- count them in instead of draining them
-#define PP_STAGE(IT, BASE, HOFF, OFF)                                                            \
-  if ((IT) < T) {                                                                                \
-    issue_half(BASE, HOFF, OFF);                                                                 \
-    if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RELAX) : "memory");                    \
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");                             \
-  } else {                                                                                       \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-  }
-// phase x (0..3) of K-tile `it` issues stream index 4 it + 1 + x + DEPTH: half X = (1 + x + DEPTH) % 4 of K-tile
-// it + (1 + x + DEPTH) / 4 (DEPTH 5: B1, A1 of it+1, then A0, B0 of it+2; DEPTH 7: A0 B0 B1 A1 of it+2)
-#define PP_STAGE_X(XP)                                                                           \
+  PP_ST(4)                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  PP_ST(5)                                                                                       \
+  PP_CNT
+// stage one half-tile and leave four half-tiles in flight: vmcnt(INFL), or vmcnt(RELAX) in the K-tile after an epilogue
+// (`relaxed` != 0): its stores were issued after the three older half-tiles still in flight -- count them in instead of
+// draining them.  One asm statement with its own two-instruction branch: an if / else in C++ made the compiler clone the
+// K-tile body (256 VGPRs + spills).
+#define PP_STAGE(PH, BASE, HOFF, OFF)                                                            \
   {                                                                                              \
-    constexpr int hx_ = 1 + (XP) + DEPTH, ko_ = hx_ / 4, X_ = hx_ % 4;                           \
-    const char* ba_ = (ko_ == 1) ? a1 : a2;                                                      \
-    const char* bb_ = (ko_ == 1) ? bb1 : bb2;                                                    \
-    if (X_ == 0) { PP_STAGE(it + ko_, ba_, 0, offA) }                                            \
-    else if (X_ == 1) { PP_STAGE(it + ko_, bb_, 0, offB) }                                       \
-    else if (X_ == 2) { PP_STAGE(it + ko_, bb_, halfB, offB) }                                   \
-    else { PP_STAGE(it + ko_, ba_, halfA, offA) }                                                \
+  PP_ST2(0)                                                                                      \
+  PP_ST3(PH)                                                                                     \
+  issue_half(BASE, HOFF, OFF);                                                                   \
+  PP_ST2(1)                                                                                      \
+  asm volatile("s_cmp_lg_u32 %0, 0\n\t"                                                          \
+               "s_cbranch_scc1 .Lpp_relaxed_%=\n\t"                                              \
+               "s_waitcnt vmcnt(%1)\n\t"                                                         \
+               "s_branch .Lpp_waited_%=\n"                                                       \
+               ".Lpp_relaxed_%=:\n\t"                                                            \
+               "s_waitcnt vmcnt(%2)\n"                                                           \
+               ".Lpp_waited_%=:" ::"s"(relaxed), "n"(INFL), "n"(RELAX) : "scc", "memory");        \
+  PP_STL(PH)                                                                                     \
   }
+// one K-tile.  Phase x issues stream index 4 it + 6 + x: B1, A1 of K-tile it+1, then A0, B0 of K-tile it+2
+#define PP_KTILE                                                                                 \
+  PP_READ_B(b0, sp + XB0 * HALF)                                                                 \
+  PP_READ_A(sp + XA0 * HALF)                                                                     \
+  PP_STAGE(0, bb1, halfB, offB)                                                                  \
+  PP_MFMA(0, 0, b0)                                                                              \
+  PP_READ_B(b1, sp + XB1 * HALF)                                                                 \
+  PP_STAGE(1, a1, halfA, offA)                                                                   \
+  PP_MFMA(0, 1, b1)                                                                              \
+  PP_READ_A(sp + XA1 * HALF)                                                                     \
+  PP_STAGE(2, a2, 0, offA)                                                                       \
+  PP_MFMA(1, 1, b1)                                                                              \
+  PP_STAGE(3, bb2, 0, offB)                                                                      \
+  PP_MFMA(1, 0, b0)
 
-  // ---- prologue: stream indices 0..DEPTH (K-tile 0, and K-tile 1 up to B0 or whole)
-  const char *a1 = nullptr, *bb1 = nullptr, *a2 = nullptr, *bb2 = nullptr;  // bases of K-tiles it+1, it+2
+  // ---- prologue: stream indices 0..5 (K-tile 0, and A0, B0 of K-tile 1)
+  static_assert(DEPTH == 5, "stage schedule written out for the 8-slot ring");
+  const char *a1, *bb1, *a2, *bb2;  // bases of K-tiles it+1, it+2 (past the end: the last K-tile again)
   {
     const char *a0, *bb0;
     cursor_next(a0, bb0);
@@ -711,72 +796,64 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     issue_half(bb0, 0, offB);
     issue_half(bb0, halfB, offB);
     issue_half(a0, halfA, offA);
-    if (1 < T) {
-      cursor_next(a1, bb1);
-      issue_half(a1, 0, offA);
-      issue_half(bb1, 0, offB);
-      if (DEPTH == 7) {
-        issue_half(bb1, halfB, offB);
-        issue_half(a1, halfA, offA);
-      }
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
-    if (2 < T) cursor_next(a2, bb2);
+    cursor_next(a1, bb1);
+    issue_half(a1, 0, offA);
+    issue_half(bb1, 0, offB);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
+    cursor_next(a2, bb2);
   }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
-  int rslot = 0;  // slot of A0 of the current K-tile (stream index 4 it)
-  auto slot_ptr = [&](int x) -> char* {
-    int sl = rslot + x;
-    if (sl >= NSLOT) sl -= NSLOT;
-    return smem + sl * HALF;
-  };
+  unsigned kb = 0;  // byte offset of the current K-tile's four slots: 0 or 4 * HALF
   int kt = 0, jt = 0;
-  bool relaxed = false;
+  int relaxed = 0;
   for (int it = 0; it < T; ++it) {
-    // P1
-    PP_READ_B(b0, slot_ptr(XB0))
-    PP_READ_A(slot_ptr(XA0))
-    PP_STAGE_X(0)
-    PP_MFMA(0, 0, b0)
-    // P2
-    PP_READ_B(b1, slot_ptr(XB1))
-    PP_STAGE_X(1)
-    PP_MFMA(0, 1, b1)
-    // P3
-    PP_READ_A(slot_ptr(XA1))
-    PP_STAGE_X(2)
-    PP_MFMA(1, 1, b1)
-    // P4
-    PP_STAGE_X(3)
-    PP_MFMA(1, 0, b0)
-    relaxed = false;
-    a1 = a2; bb1 = bb2;
-    if (it + 3 < T) cursor_next(a2, bb2);
+    const char* sp = smem + kb;
+    PP_KTILE
+    relaxed = 0;
+    a1 = a2;
+    bb1 = bb2;
+    cursor_next(a2, bb2);
+    kb ^= 4 * HALF;
     if (++kt == nk) {
       kt = 0;
       int tm, tn;
       tile_coords(jt, tm, tn);
       ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
-      char* scr = (NSLOT == 8) ? smem + 8 * HALF + wave * SCR : slot_ptr(wave < 4 ? XB1 : XA1) + (wave & 3) * SCR;
+      char* scr = smem + 8 * HALF + wave * SCR;
+#ifdef VIT_PP_DIAG
+      if (p.debug & 128) {
+        if (acc[0][0][0] == 1.2345f) p.C[0] = 1;  // keep the accumulators alive
+      } else
+#endif
       if constexpr (EPI >= 3) pp_epilogue<EPI, 8>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       else tile_epilogue<8, 4, CW, EPI>(acc, scr, p, tm * BM + wr * 128, tn * BN + wc * 64, split, lane);
       if (grp == 1) __builtin_amdgcn_s_barrier();  // re-stagger
-      relaxed = true;
+      relaxed = 1;
+      PP_ST(6)
     }
-    rslot += 4;
-    if (rslot >= NSLOT) rslot -= NSLOT;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier of the other group
+#ifdef VIT_PP_STAMP
+  if (p.stamps && (int)blockIdx.x == p.stamp_block && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.stamps[wave * 8 + k] = st_[k];
+  }
+#endif
+#undef PP_ST
+#undef PP_ST2
+#undef PP_ST3
+#undef PP_STL
+#undef PP_STX
+#undef PP_CNT
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_MFMA
 #undef PP_STAGE
-#undef PP_STAGE_X
+#undef PP_KTILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of the walk are still landing in the LDS
 }
 
 // ------------------------------------------------------------------------------------------------ half-tile tail kernel
@@ -958,7 +1035,6 @@ static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
   return launch_half<0, 1, 6>(a, st);
 }
 
-int g_krot = 0;  // vit_set_option("gemm_krot"): 0 = off, 1 = automatic K-walk rotation step, >1 = that step
 int g_grp2 = 1;  // vit_set_option("gemm_ngroups"): 1 = two N-groups for weights larger than an L2 (see tile_coords)
 int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
@@ -978,7 +1054,7 @@ static int launch_stag_n(const Gemm2Args& a, dim3 grid, hipStream_t st) {
 }
 template <int AT, int BT, int EPI>
 static int launch_stag(const Gemm2Args& a, dim3 grid, hipStream_t st) {
-  return g_pp_slots == 8 ? launch_stag_n<AT, BT, EPI, 8>(a, grid, st) : launch_stag_n<AT, BT, EPI, 10>(a, grid, st);
+  return launch_stag_n<AT, BT, EPI, 8>(a, grid, st);
 }
 static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
   if (epi == 1) return launch_stag<0, 0, 1>(a, grid, st);
@@ -995,6 +1071,10 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
 }
 
 extern thread_local int g_colsum_fused;  // gemm.hip
+#ifdef VIT_PP_STAMP
+unsigned long long* g_pp_stamps = nullptr;
+int g_pp_stamp_block = 0;
+#endif
 int g_gemm2_mode = -1;  // -1: read VIT_GEMM2 from the environment on first use
 int g_gemm2_debug = 0;
 
@@ -1076,6 +1156,10 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.drop = make_drop_h(h, d->dropout_p, d->seed, d->site);
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
   a.debug = g_gemm2_debug;
+#ifdef VIT_PP_STAMP
+  a.stamps = g_pp_stamps;
+  a.stamp_block = g_pp_stamp_block;
+#endif
 
   dim3 grid(a.nblk, splits);
   a.lin_split = 0;
@@ -1107,14 +1191,6 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.nblk = cdiv(ntile - half_tail, cdiv(ntile - half_tail, slots));
     grid = dim3(a.nblk, splits);
   }
-  a.krot = 0;
-  if (cfg == 5 && g_krot) {
-    const int nk_ = (splits > 1 ? a.k_per_split : d->K) / 64;
-    // sharers of a panel: tiles_n for A, tiles_m for B (per K-slice); spread them evenly over the K-tiles
-    const int sharers = std::max(1, std::min(std::max(a.tiles_m, a.tiles_n), nk_));
-    a.krot = g_krot > 0 ? std::max(1, nk_ / sharers) : 0;
-    if (g_krot > 1) a.krot = g_krot;
-  }
   a.grp2 = 0;
   if (cfg == 5 && g_grp2 && splits == 1 && !half_tail && !a.lin_split && (a.tiles_n % 2) == 0 &&
       (size_t)d->N * d->K * 2 > (size_t)4 << 20 && ntile > slots && (ntile % 2) == 0) {
@@ -1137,7 +1213,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   {
     static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
-    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, g_pp_slots == 8 ? 8 : 10);
+    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, 8);
     else snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", geo[cfg][0], geo[cfg][1],
                   geo[cfg][2], geo[cfg][3], geo[cfg][4], at, bt, epi);
   }
