@@ -771,8 +771,9 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
                ".Lpp_waited_%=:" ::"s"(relaxed), "n"(INFL), "n"(RELAX) : "scc", "memory");        \
   PP_STL(PH)                                                                                     \
   }
-// one K-tile.  Phase x issues stream index 4 it + 6 + x: B1, A1 of K-tile it+1, then A0, B0 of K-tile it+2
-#define PP_KTILE                                                                                 \
+// Two forms of one K-tile, chosen per operand layout (MERGED below).
+// FOUR phases of 16 MFMAs.  Phase x issues stream index 4 it + 6 + x: B1, A1 of K-tile it+1, then A0, B0 of K-tile it+2
+#define PP_KTILE4                                                                                \
   PP_READ_B(b0, sp + XB0 * HALF)                                                                 \
   PP_READ_A(sp + XA0 * HALF)                                                                     \
   PP_STAGE(0, bb1, halfB, offB)                                                                  \
@@ -785,6 +786,57 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   PP_MFMA(1, 1, b1)                                                                              \
   PP_STAGE(3, bb2, 0, offB)                                                                      \
   PP_MFMA(1, 0, b0)
+// TWO phases per K-tile, 32 MFMAs each (half the barriers):
+//   I   reads B0, A0, B1 (16 fragments)  issues A1 of K-tile it+1           MFMA (A0,B0), (A0,B1)
+//   II  reads A1 (8 fragments)           issues A0, B0, B1 of K-tile it+2   MFMA (A1,B1), (A1,B0)
+// Stream order A0 B0 B1 A1 as before; every wait leaves four half-tiles in flight: after I the newest four are A0 B0 B1 A1
+// of K-tile it+1, so A1(it) has landed (read in II); after II they are A1(it+1), A0 B0 B1(it+2), so A0 B0 B1 of it+1 have
+// landed (read in the next I).  Slot reuse: the wait for a phase's fragment reads (lgkmcnt) sits BEFORE the barrier that
+// ends its LOAD segment, so when that barrier releases the fragments are in registers; A0 B0 B1 of K-tile it are read in
+// phase I by both groups (the staggered group's LOAD segment ends one barrier later, still before the other group's
+// phase-II LOAD segment starts issuing their replacements), A1(it) in phase II, replaced from phase I of it+1.
+#define PP_LOADED(RX)                                                                            \
+  asm volatile("s_cmp_lg_u32 %0, 0\n\t"                                                          \
+               "s_cbranch_scc1 .Lpp_relaxed_%=\n\t"                                              \
+               "s_waitcnt vmcnt(%1)\n\t"                                                         \
+               "s_branch .Lpp_waited_%=\n"                                                       \
+               ".Lpp_relaxed_%=:\n\t"                                                            \
+               "s_waitcnt vmcnt(%2)\n"                                                           \
+               ".Lpp_waited_%=:\n\t"                                                             \
+               "s_waitcnt lgkmcnt(0)" ::"s"(relaxed), "n"(INFL), "n"(RX) : "scc", "memory");
+#define PP_MFMA2(HA, BFA, HBA, BFB, HBB)                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  PP_SETPRIO1                                                                                    \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+          acc[HA * 4 + i_][HBA * 2 + j_] =                                                       \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFA[j_][s_], af[i_][s_], acc[HA * 4 + i_][HBA * 2 + j_], 0, 0, 0); \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
+          acc[HA * 4 + i_][HBB * 2 + j_] =                                                       \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFB[j_][s_], af[i_][s_], acc[HA * 4 + i_][HBB * 2 + j_], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  __builtin_amdgcn_s_barrier();
+#define PP_KTILE2                                                                                \
+  PP_READ_B(b0, sp + XB0 * HALF)                                                                 \
+  PP_READ_A(sp + XA0 * HALF)                                                                     \
+  PP_READ_B(b1, sp + XB1 * HALF)                                                                 \
+  issue_half(a1, halfA, offA);                                                                   \
+  PP_LOADED(RELAX)                                                                               \
+  PP_MFMA2(0, b0, 0, b1, 1)                                                                      \
+  PP_READ_A(sp + XA1 * HALF)                                                                     \
+  issue_half(a2, 0, offA);                                                                       \
+  issue_half(bb2, 0, offB);                                                                      \
+  issue_half(bb2, halfB, offB);                                                                  \
+  PP_LOADED(RELAX)                                                                               \
+  PP_MFMA2(1, b1, 1, b0, 0)
+  // Measured per layout (tools/gemm_bench.py, ViT-B layer shapes): the two-phase form is worth 11-17 % on dW (both
+  // operands through the transposing reads: its 24-instruction LOAD segments were the long pole of a 16-MFMA interval) and
+  // 1-2 % on dX; the forward GEMMs (K = 768: an epilogue every 12 K-tiles) are 0-4 % FASTER with four phases.
+  constexpr bool MERGED = A_T || B_T;
 
   // ---- prologue: stream indices 0..5 (K-tile 0, and A0, B0 of K-tile 1)
   static_assert(DEPTH == 5, "stage schedule written out for the 8-slot ring");
@@ -799,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     cursor_next(a1, bb1);
     issue_half(a1, 0, offA);
     issue_half(bb1, 0, offB);
+    if constexpr (MERGED) issue_half(bb1, halfB, offB);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFL) : "memory");
     cursor_next(a2, bb2);
   }
@@ -810,7 +863,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   int relaxed = 0;
   for (int it = 0; it < T; ++it) {
     const char* sp = smem + kb;
-    PP_KTILE
+    if constexpr (MERGED) {
+      PP_KTILE2
+    } else {
+      PP_KTILE4
+    }
     relaxed = 0;
     a1 = a2;
     bb1 = bb2;
@@ -852,7 +909,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #undef PP_READ_B
 #undef PP_MFMA
 #undef PP_STAGE
-#undef PP_KTILE
+#undef PP_KTILE2
+#undef PP_KTILE4
+#undef PP_LOADED
+#undef PP_MFMA2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end of the walk are still landing in the LDS
 }
 
