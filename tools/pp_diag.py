@@ -8,6 +8,8 @@ disappears when it alone is removed, and the time of the kernel that has only th
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if len(sys.argv) > 2:  # pp_diag.py epi <tag>: a compile-time variant build (python -m vit_amd.build --defs ... --tag <tag>)
+    os.environ["VIT_AMD_LIB"] = os.path.join(ROOT, "vit_amd", "lib", f"libvit_amd_{sys.argv[2]}.so" if sys.argv[2] != "prod" else "libvit_amd.so")
 os.environ.setdefault("VIT_AMD_LIB", os.path.join(ROOT, "vit_amd", "lib", "libvit_amd_diag.so"))
 import torch
 import vit_amd.functional as vf
@@ -43,8 +45,17 @@ def t(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-masks = [(0, "full"), (16, "-dma"), (32, "-reads"), (64, "-mfma"), (128, "-epi"), (16 | 32, "mfma+epi"), (32 | 64, "dma+epi"),
+if len(sys.argv) > 1 and sys.argv[1] == "epi":
+    masks = [(0, sys.argv[2] if len(sys.argv) > 2 else "full")]
+else:
+  masks = [(0, "full"), (16, "-dma"), (32, "-reads"), (64, "-mfma"), (128, "-epi"), (16 | 32, "mfma+epi"), (32 | 64, "dma+epi"),
          (16 | 64, "reads+epi"), (16 | 32 | 64, "barriers+epi"), (16 | 32 | 64 | 128, "barriers")]
+W2 = R(D, F)
+o3072 = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+aux = torch.empty(M, F, device=dev, dtype=torch.bfloat16)
+b3072 = torch.zeros(F, device=dev)
+cases["NT fc1 fwd +gelu,aux N=3072"] = (lambda: vf.gemm(x768, W1, M=M, N=F, K=D, bias=b3072, act=_cabi.ACT_GELU_GRAD, aux_out=aux, out=o3072), 2 * M * F * D)
+cases["NN dX fc2 *aux N=3072 K=768"] = (lambda: vf.gemm(dy768, W2, M=M, N=F, K=D, b_trans=True, act=_cabi.ACT_MUL_AUX, aux_in=aux, out=o3072), 2 * M * F * D)
 print("kernel:", end=" ")
 for name, (fn, fl) in cases.items():
     _cabi.set_option("gemm_debug", 0)

@@ -386,17 +386,27 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
         for (int rr = 0; rr < 2; ++rr)
           au[ii][rr] = *(const u32x4*)(p.aux_in + (long)(m0 + (i + ii) * 16 + rr * 8 + rsub) * p.ldaux + n);
     }
+    f32x4 v[2][2];
+#ifdef VIT_EPI_NOLDS  // timing experiment (compile-time variant): no LDS transpose, values land in the wrong places
+    {
+      v[0][0] = acc[i][0]; v[0][1] = acc[i][1]; v[1][0] = acc[i][2]; v[1][1] = acc[i][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (false)
+#endif
+    {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *(f32x4*)(scr + l15 * 256 + (((j * 4 + lg) ^ l15) << 4)) = acc[i][j];
       acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 v[2][2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int row = rr * 8 + rsub;
       v[rr][0] = *(const f32x4*)(scr + row * 256 + (((2 * cg) ^ row) << 4));
       v[rr][1] = *(const f32x4*)(scr + row * 256 + (((2 * cg + 1) ^ row) << 4));
+    }
     }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -880,7 +890,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
       ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
       char* scr = smem + 8 * HALF + wave * SCR;
-#ifdef VIT_PP_DIAG
+#if defined(VIT_EPI_NONE)  // timing experiment (compile-time variant): no epilogue at all
+      if (true) {
+        if (acc[0][0][0] == 1.2345f) p.C[0] = 1;  // keep the accumulators alive
+      } else
+#elif defined(VIT_PP_DIAG)
       if (p.debug & 128) {
         if (acc[0][0][0] == 1.2345f) p.C[0] = 1;  // keep the accumulators alive
       } else
