@@ -979,19 +979,30 @@ __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
     }
   }
   const long halfA = ((A_T == 0) ? 64 * p.lda : 64) * h, halfB = (B_T == 0) ? 32 * p.ldb : 32;
-  const char* a_base = (A_T == 0) ? p.A + ((long)tm * BM * p.lda) * 2 : p.A + ((long)tm * BM) * 2;
-  const char* b_base = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb) * 2 : p.B + ((long)tn * BN) * 2;
-  const long kstepA = (A_T == 0) ? BK : (long)BK * p.lda, kstepB = (B_T == 0) ? BK : (long)BK * p.ldb;  // elements per K-tile
+  // operand bases of the next K-tile to stage, advanced by a constant per K-tile; past the last K-tile they stay (the
+  // re-fetched half-tiles land in ring slots nobody reads again), so no phase carries an "is there a next K-tile" branch --
+  // the same scalar diet as gemm3_kernel's loop (one instruction per ~4-5 cycles per wave: bookkeeping is not free)
+  const char* ca = ((A_T == 0) ? p.A + ((long)tm * BM * p.lda) * 2 : p.A + ((long)tm * BM) * 2) + halfA * 2;
+  const char* cb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb) * 2 : p.B + ((long)tn * BN) * 2;
+  const long dA = (A_T == 0) ? (long)BK * 2 : (long)BK * p.lda * 2, dB = (B_T == 0) ? (long)BK * 2 : (long)BK * p.ldb * 2;
+  int ckt = 0;
+  auto cursor_next = [&](const char*& ab, const char*& bb) {
+    ab = ca;
+    bb = cb;
+    if (ckt + 1 < nk) {
+      ++ckt;
+      ca += dA;
+      cb += dB;
+    }
+  };
 
-  int islot = 0;
+  unsigned dofs = 0;
   auto issue_half = [&](const char* base, long off_el, const int (&off)[2]) {
-    char* dst = smem + islot * HALF + wave * 1024;
-    islot = (islot + 1) & (NSLOT - 1);
+    char* dst = smem + dofs + wave * 1024;
+    dofs = (dofs + HALF) & (NSLOT * HALF - 1);
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
   };
-  auto issue_A = [&](int kt) { issue_half(a_base, kt * kstepA + halfA, offA); };
-  auto issue_B = [&](int kt, int hb) { issue_half(b_base, kt * kstepB + hb * halfB, offB); };
 
   const int tq = l15 >> 2, tp = l15 & 3;
   const int tr_f = (tq | ((lg & 1) << 2)) << 2;
@@ -1031,24 +1042,28 @@ __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
   __builtin_amdgcn_s_barrier();
 
   // prologue: everything first read in phases 1..3 = A B0 B1 of K-tile 0, A B0 of K-tile 1 (stream indices 0..4)
-  issue_A(0);
-  issue_B(0, 0);
-  issue_B(0, 1);
-  if (1 < nk) {
-    issue_A(1);
-    issue_B(1, 0);
+  const char *a1, *b1, *a2, *b2;  // bases of K-tiles kt + 1, kt + 2 (clamped to the last one)
+  {
+    const char *a0, *b0;
+    cursor_next(a0, b0);
+    issue_half(a0, 0, offA);
+    issue_half(b0, 0, offB);
+    issue_half(b0, halfB, offB);
+    cursor_next(a1, b1);
+    issue_half(a1, 0, offA);
+    issue_half(b1, 0, offB);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    cursor_next(a2, b2);
   }
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
-  int rslot = 0;  // slot of A of the current K-tile (stream index 3 kt)
+  unsigned rofs = 0;  // byte offset of A of the current K-tile in the ring (stream index 3 kt)
+  constexpr unsigned RING = NSLOT * HALF - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    const char* sA = smem + rslot * HALF;
-    const char* sB0 = smem + ((rslot + 1) & 7) * HALF;
-    const char* sB1 = smem + ((rslot + 2) & 7) * HALF;
+    const char* sA = smem + rofs;
+    const char* sB0 = smem + ((rofs + HALF) & RING);
+    const char* sB1 = smem + ((rofs + 2 * HALF) & RING);
     // P1 = (A, B0); issues B1 of K-tile kt + 1 (first read three phases on)
 #pragma unroll
     for (int j_ = 0; j_ < 2; ++j_)
@@ -1058,28 +1073,24 @@ __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
     for (int i_ = 0; i_ < 4; ++i_)
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) af[i_][s_] = read_frag(sA, A_T, wr * 64 + i_ * 16, s_);
-    if (kt + 1 < nk) {
-      issue_B(kt + 1, 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    issue_half(b1, halfB, offB);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     HT_MFMA(0)
     // P2 = (A, B1); issues A and B0 of K-tile kt + 2
 #pragma unroll
     for (int j_ = 0; j_ < 2; ++j_)
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) bq[j_][s_] = read_frag(sB1, B_T, wc * 32 + j_ * 16, s_);
-    if (kt + 2 < nk) {
-      issue_A(kt + 2);
-      issue_B(kt + 2, 0);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    issue_half(a2, 0, offA);
+    issue_half(b2, 0, offB);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     HT_MFMA(1)
-    rslot = (rslot + 3) & 7;
+    rofs = (rofs + 3 * HALF) & RING;
+    a1 = a2;
+    b1 = b2;
+    cursor_next(a2, b2);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped re-fetches are still landing in the ring
   if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier: everyone is done with the ring
 #undef HT_MFMA
   char* scr = smem + 8 * HALF + wave * SCR;
