@@ -84,14 +84,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // third partial row -- what vit_dropout_bwd_cast + vit_colsum would otherwise re-read dx for.
 // FUSE: 0 = plain, 1 = + bf16 dyn, 2 = + f32 dyn
 template <int NV, int DY_BF16, int FUSE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part, int rows, int D,
                                                      void* __restrict__ dyn, DropCfg drop) {
   resolve_drop(drop);
   constexpr int NP = FUSE ? 3 : 2;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][D]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NP][D], used by four waves at a time
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -161,22 +161,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       }
     }
   }
-  // block combine
+  // block combine, four waves at a time through the same 4 x NP x D floats (a 16-wave block = one partial row per CU: 256
+  // rows for the reducer instead of 1024, no first reduction stage); each thread owns the columns tid, tid + blockDim, ...
+  const int nw = blockDim.x >> 6, ngrp = (nw + 3) >> 2;
+  constexpr int KMAX = 16;  // columns per thread: NP * D <= 4096 = 16 * 256 at every shape the dispatch accepts
+  float tot[KMAX];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-      *(f32x4*)(red + (wib * NP + 0) * D + 4 * c) = dg[i];
-      *(f32x4*)(red + (wib * NP + 1) * D + 4 * c) = db[i];
-      if (FUSE) *(f32x4*)(red + (wib * NP + 2) * D + 4 * c) = dbias[i];
+  for (int k = 0; k < KMAX; ++k) tot[k] = 0.f;
+  for (int gq = 0; gq < ngrp; ++gq) {
+    if ((wib >> 2) == gq) {
+      const int w4 = wib & 3;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+          *(f32x4*)(red + (w4 * NP + 0) * D + 4 * c) = dg[i];
+          *(f32x4*)(red + (w4 * NP + 1) * D + 4 * c) = db[i];
+          if (FUSE) *(f32x4*)(red + (w4 * NP + 2) * D + 4 * c) = dbias[i];
+        }
+      }
     }
+    __syncthreads();
+    const int nw4 = min(4, nw - gq * 4);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      if (i < NP * D) {
+        float a = 0.f;
+        for (int w = 0; w < nw4; ++w) a += red[w * NP * D + i];
+        tot[k] += a;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const int nw = blockDim.x >> 6;
-  for (int i = threadIdx.x; i < NP * D; i += blockDim.x) {
-    float a = 0.f;
-    for (int w = 0; w < nw; ++w) a += red[w * NP * D + i];
-    part[(long)blockIdx.x * NP * D + i] = a;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    if (i < NP * D) part[(long)blockIdx.x * NP * D + i] = tot[k];
   }
 }
 
@@ -199,12 +220,12 @@ static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void*
 
 template <int DY_BF16, int FUSE>
 static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const float* mean, const float* rstd,
-                           const float* dres, float* dx, float* part, int rows, int D, int blocks, void* dyn,
-                           DropCfg drop, hipStream_t st) {
+                           const float* dres, float* dx, float* part, int rows, int D, int blocks, int threads,
+                           void* dyn, DropCfg drop, hipStream_t st) {
   const int nv = cdiv(D, 256);
   const size_t sh = (size_t)4 * (FUSE ? 3 : 2) * D * sizeof(float);
   if (sh > 64 * 1024) { set_error("vit_layernorm_bwd: D=%d needs %zu bytes of LDS", D, sh); return VIT_ERR_UNSUPPORTED; }
-#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16, FUSE>), dim3(blocks), dim3(256), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D, dyn, drop)
+#define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16, FUSE>), dim3(blocks), dim3(threads), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D, dyn, drop)
   if (nv <= 1) LAUNCH(1);
   else if (nv <= 2) LAUNCH(2);
   else if (nv <= 3) LAUNCH(3);
@@ -220,23 +241,27 @@ static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float
                          const float* mean, const float* rstd, const float* dres, float* dx, float* dgamma,
                          float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, DropCfg drop,
                          hipStream_t st) {
-  // 4 blocks of 4 waves per CU: the block-combine LDS (4 waves x 3 x D floats = 36 KiB at D = 768) allows four, and with
-  // only two waves per SIMD (512 blocks) the pass was latency-bound at 4.3 TB/s (bytes in flight / HBM latency)
-  const int blocks = std::min(cdiv(rows, 16), 1024);
+  // 16 waves per CU: with only two waves per SIMD the pass was latency-bound at 4.3 TB/s (bytes in flight / HBM latency).
+  // They are ONE block of 1024 threads per CU when there are rows for it: its waves combine through the LDS four at a time
+  // (36 KiB at D = 768), so the pass leaves 256 partial rows instead of 1024 and the reducer needs no first stage (25
+  // launches of 7 us per step).  Small inputs keep 4-wave blocks (up to 4 per CU).
   const int np = dyn ? 3 : 2;
+  const bool big = rows >= 256 * 16;
+  const int threads = big ? 1024 : 256;
+  const int blocks = big ? 256 : std::min(cdiv(rows, 16), 1024);
   size_t wsb = 0;
   float* part = (float*)ctx_workspace(h, &wsb);
   const size_t need = (size_t)blocks * np * D * sizeof(float);
   VIT_CHECK(part && wsb >= need, VIT_ERR_WORKSPACE, "vit_layernorm_bwd: needs %zu workspace bytes, have %zu", need, wsb);
   int rc;
   if (dyn && dyn_dtype == VIT_BF16)
-    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
-                              : ln_bwd_dispatch<0, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st)
+                              : ln_bwd_dispatch<0, 1>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st);
   else if (dyn)
-    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
-                              : ln_bwd_dispatch<0, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
-  else rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st)
-                                 : ln_bwd_dispatch<0, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, dyn, drop, st);
+    rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st)
+                              : ln_bwd_dispatch<0, 2>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st);
+  else rc = dy_dtype == VIT_BF16 ? ln_bwd_dispatch<1, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st)
+                                 : ln_bwd_dispatch<0, 0>(dy, x, gamma, mean, rstd, dres, dx, part, rows, D, blocks, threads, dyn, drop, st);
   if (rc != VIT_OK) return rc;
   if (!dyn) return launch_reduce_partials(part, blocks, 2 * D, dgamma, D, dbeta, 0, st, np * D);
   return launch_reduce_partials(part, blocks, 3 * D, dgamma, D, dbeta, 0, st, np * D, 2 * D, dbias);  // one launch for all three
