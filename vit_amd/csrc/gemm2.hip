@@ -813,11 +813,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
                ".Lpp_relaxed_%=:\n\t"                                                            \
                "s_waitcnt vmcnt(%2)\n"                                                           \
                ".Lpp_waited_%=:\n\t"                                                             \
-               "s_waitcnt lgkmcnt(0)" ::"s"(relaxed), "n"(INFL), "n"(RX) : "scc", "memory");
+               "s_waitcnt lgkmcnt(0)" ::"s"(relaxed), "n"(INFL), "n"(RX) : "scc", "memory");       \
+  PP_ST(2)
 #define PP_MFMA2(HA, BFA, HBA, BFB, HBB)                                                         \
   __builtin_amdgcn_sched_barrier(0);                                                             \
   __builtin_amdgcn_s_barrier();                                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                             \
+  PP_ST(3)                                                                                       \
   PP_SETPRIO1                                                                                    \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) \
       _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                            \
@@ -829,7 +831,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFB[j_][s_], af[i_][s_], acc[HA * 4 + i_][HBB * 2 + j_], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                 \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  __builtin_amdgcn_s_barrier();
+  PP_ST(4)                                                                                       \
+  __builtin_amdgcn_s_barrier();                                                                  \
+  PP_ST(5)                                                                                       \
+  PP_CNT
 #define PP_KTILE2                                                                                \
   PP_READ_B(b0, sp + XB0 * HALF)                                                                 \
   PP_READ_A(sp + XA0 * HALF)                                                                     \
