@@ -419,6 +419,12 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
       }
       if (FAST == 4) {
         float sv[8];  // aux_out: the pre-activation (ACT_GELU) or gelu' of it (ACT_GELU_GRAD: two FMAs on top of the GELU)
+#ifdef VIT_EPI_NOGELU  // timing experiment: no GELU arithmetic (values are wrong)
+        if (true) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) sv[r] = o[r] * 0.5f;
+        } else
+#endif
         if (p.act == VIT_ACT_GELU_GRAD) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
@@ -434,7 +440,11 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
             o[r] = gelu_erf(o[r]);
           }
         }
+#ifdef VIT_EPI_NOAUX  // timing experiment: the second output is not stored
+        if (p.aux_out && sv[0] == 1.2345e30f) {
+#else
         if (p.aux_out) {
+#endif
           u32x4 pk = {pack2bf(sv[0], sv[1]), pack2bf(sv[2], sv[3]), pack2bf(sv[4], sv[5]), pack2bf(sv[6], sv[7])};
           *(u32x4*)(p.aux_out + m * p.ldaux + n) = pk;
         }
