@@ -68,9 +68,8 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                tile; 0 = one launch.
  *   "gemm_balance_wgs": 1 (default) = a multi-round ping-pong GEMM launches ceil(tiles / rounds) workgroups instead of 256
  *                (same makespan in tile-times, idle CUs instead of CUs that idle for the last round); 0 = always 256.
- *   "gemm_pp_slots": 8 (default) or 10 half-tile slots in the ping-pong core's LDS ring: 64 or 96 KiB of operand
- *                loads in flight per CU (10 puts the epilogue scratch on ring slots that are free at a tile boundary;
- *                measured 0-15 % slower on the ViT-B shapes: the loop is not bound by bytes in flight).
+ *   "gemm_pp_slots": 8 (the only value since round 2: the 10-slot ring, 96 KiB of operand loads in flight per CU, measured
+ *                0-15 % slower on the ViT-B shapes and was removed with the K-loop rewrite; any other value is VIT_ERR_ARG).
  *   "gemm_debug": timing diagnostics for the LDS-DMA core (1 = skip operand DMA after the prologue, 2 = skip MFMAs);
  *                results are meaningless while it is non-zero.
  *                Returns VIT_ERR_ARG for an unknown name. */

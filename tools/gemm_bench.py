@@ -26,7 +26,7 @@ def main():
         core, _, bal = core.partition("b")
         core, _, slots = core.partition("s")
         _cabi.set_option("gemm_core", int(core))
-        _cabi.set_option("gemm_pp_slots", int(slots) if slots else 8)
+        _cabi.set_option("gemm_pp_slots", 8)  # the 10-slot ring is gone
         _cabi.set_option("gemm_balance_wgs", int(bal) if bal else 1)
         _cabi.set_option("gemm_half_tail", int(half) if half else 1)
     dev = torch.device("cuda:0")
