@@ -33,7 +33,8 @@ cases = {
 }
 names3 = ["reads landed P1 (12)", "P2 (4)", "P3 (8)", "P4 (0)", "DMA issue + vmcnt", "barrier+lgkm", "MFMA seg + closing barrier + epilogue"]
 names4 = ["LOAD segment P1 (+loop tail)", "P2", "P3", "P4", "barrier+lgkm", "MFMA segment", "closing barrier + epilogue"]
-names = names4 if level == 4 else names3 if level == 3 else ["reads landed", "DMA issue", "vmcnt wait" if level >= 2 else "LOAD segment", "barrier+lgkm", "MFMA segment",
+names5 = ["P1 LOAD segment incl. loop tail (per K-tile)", "everything else (per K-tile)", "", "", "", "", ""]
+names = names5 if level == 5 else names4 if level == 4 else names3 if level == 3 else ["reads landed", "DMA issue", "vmcnt wait" if level >= 2 else "LOAD segment", "barrier+lgkm", "MFMA segment",
          "closing barrier", "epilogue"]
 buf = torch.zeros(64, dtype=torch.int64, device=dev)
 for name, fn in cases.items():
@@ -50,7 +51,7 @@ for name, fn in cases.items():
         for w in (0, 4):
             tot = float(b[w, :7].sum())
             nph = max(1, int(b[w, 7]))
-            per = (lambda k: nph / 4 if (level in (3, 4) and k < 4) else nph)
+            per = (lambda k: nph / 4 if (level in (3, 4) and k < 4) or level == 5 else nph)
             parts = " | ".join(f"{names[k]} {float(b[w, k]) / per(k):6.1f} ({100 * float(b[w, k]) / tot:4.1f}%)" for k in range(7)
-                              if level >= 2 or k >= 2)
+                              if (level >= 2 or k >= 2) and names[k])
             print(f"{name} wg {block:3d} wave {w}: {nph:4d} phases, {tot / nph:6.1f} ticks/phase: {parts}", flush=True)

@@ -706,7 +706,23 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
     tprev_ = t_;                                                                                 \
   }
 #define PP_CNT st_[7] += 1;
-#if VIT_PP_STAMP == 4
+#if VIT_PP_STAMP == 5
+// level 5 (least intrusive): a stamp after every closing barrier (slot 1 = everything else) and ONE more at the end of P1's
+// LOAD segment: slot 0 = loop tail + P1's fragment reads + its LDS-DMA issue + counted wait
+#define PP_ST(K) PP_ST5_##K
+#define PP_ST5_2
+#define PP_ST5_3
+#define PP_ST5_4
+#define PP_ST5_5 PP_STX(1)
+#define PP_ST5_6 PP_STX(1)
+#define PP_ST2(K)
+#define PP_ST3(PH)
+#define PP_STL(PH) PP_STL5_##PH
+#define PP_STL5_0 PP_STX(0)
+#define PP_STL5_1
+#define PP_STL5_2
+#define PP_STL5_3
+#elif VIT_PP_STAMP == 4
 // level 4: slots 0-3 = the whole LOAD segment of phases P1..P4 (P1 includes the loop tail), 4 = barrier + lgkmcnt,
 // 5 = MFMA segment, 6 = closing barrier + epilogue
 #define PP_ST(K) PP_STX(((K) == 3 ? 4 : (K) == 4 ? 5 : 6))
@@ -884,25 +900,26 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
   unsigned kb = 0;  // byte offset of the current K-tile's four slots: 0 or 4 * HALF
-  int kt = 0, jt = 0;
   int relaxed = 0;
-  for (int it = 0; it < T; ++it) {
-    const char* sp = smem + kb;
-    if constexpr (MERGED) {
-      PP_KTILE2
-    } else {
-      PP_KTILE4
+  // tile loop around a K loop: the K loop's body is contiguous code with ONE backward branch per K-tile (with the epilogue
+  // inside a flat loop every K-tile jumped over ~8 KB of epilogue code and back: two far taken branches on the P1 critical path)
+  for (int jt = 0; jt < my_tiles; ++jt) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sp = smem + kb;
+      if constexpr (MERGED) {
+        PP_KTILE2
+      } else {
+        PP_KTILE4
+      }
+      relaxed = 0;
+      a1 = a2;
+      bb1 = bb2;
+      cursor_next(a2, bb2);
+      kb ^= 4 * HALF;
     }
-    relaxed = 0;
-    a1 = a2;
-    bb1 = bb2;
-    cursor_next(a2, bb2);
-    kb ^= 4 * HALF;
-    if (++kt == nk) {
-      kt = 0;
+    {
       int tm, tn;
       tile_coords(jt, tm, tn);
-      ++jt;
       if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align: the other group finishes its last MFMA segment
       char* scr = smem + 8 * HALF + wave * SCR;
 #if defined(VIT_EPI_NONE)  // timing experiment (compile-time variant): no epilogue at all
