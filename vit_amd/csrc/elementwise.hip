@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_stage1_kernel(float* __r
 int launch_reduce_partials(const float* part, int nblk, int width, float* out0, int split, float* out1, int accumulate,
                            hipStream_t st, int stride, int split2, float* out2) {
   if (!stride) stride = width;
-  if (nblk > 256) {
+  if (nblk > 512) {
     // a tall partial matrix (one row per wave of the attention backward, per block of the LayerNorm backward): 36 blocks
     // of one launch left most CUs idle; fold groups of rows first, in place, then reduce the group sums (fixed order)
     const int groups = std::min(32, nblk / 32), chunk = cdiv(nblk, groups);

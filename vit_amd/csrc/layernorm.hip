@@ -242,13 +242,14 @@ static int ln_bwd_common(vit_handle h, const void* dy, int dy_dtype, const float
                          float* dbeta, int rows, int D, void* dyn, int dyn_dtype, float* dbias, DropCfg drop,
                          hipStream_t st) {
   // 16 waves per CU: with only two waves per SIMD the pass was latency-bound at 4.3 TB/s (bytes in flight / HBM latency).
-  // They are ONE block of 1024 threads per CU when there are rows for it: its waves combine through the LDS four at a time
-  // (36 KiB at D = 768), so the pass leaves 256 partial rows instead of 1024 and the reducer needs no first stage (25
-  // launches of 7 us per step).  Small inputs keep 4-wave blocks (up to 4 per CU).
+  // They are TWO blocks of 512 threads per CU when there are rows for it: a block's waves combine through the LDS four at a
+  // time (36 KiB at D = 768), so the pass leaves 512 partial rows instead of 1024 and the reducer needs no first stage (25
+  // launches of 7 us per step).  Pass + reducers on one box: 4-wave blocks and two reducer stages ~123 us, one 16-wave block
+  // per CU 126.1 us (the pass itself got 5 % slower), 8-wave blocks 122.0 us.  Small inputs keep 4-wave blocks.
   const int np = dyn ? 3 : 2;
   const bool big = rows >= 256 * 16;
-  const int threads = big ? 1024 : 256;
-  const int blocks = big ? 256 : std::min(cdiv(rows, 16), 1024);
+  const int threads = big ? 512 : 256;
+  const int blocks = big ? 512 : std::min(cdiv(rows, 16), 1024);
   size_t wsb = 0;
   float* part = (float*)ctx_workspace(h, &wsb);
   const size_t need = (size_t)blocks * np * D * sizeof(float);
