@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <math.h>
 
+#include <type_traits>
 #include "common.h"
 
 namespace vit {
@@ -556,7 +557,7 @@ __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, i
 }
 
 template <int DH, int RQ>
-__global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
+__global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
@@ -604,41 +605,40 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
   const float c = p.scale * LOG2E;
   const unsigned half_cols = (unsigned)((T + 1) >> 1);
 
-  for (int kt = 0; kt < ntl; ++kt) {
+  // One 64-key tile.  NJ = its 16-key blocks that hold keys (compile-time: the full tiles run a body with no validity test,
+  // no -inf fills and no edge select at all; the LAST tile runs the body for its own block count, so a T = 197 head does
+  // 3 x 4 + 1 blocks of softmax / dropout work instead of 4 x 4), EDGE = the last block straddles T (per-key select).
+  // Blocks that are left out would have contributed exp(-inf) = 0 to the row sums and zero rows to P V: same results.
+  auto tile = [&](auto njc, auto edgec, int kt) {
+    constexpr int NJ = decltype(njc)::value;
+    constexpr bool EDGE = decltype(edgec)::value;
     const int kb = kt * RT;
     const char* Kt = Kimg + kt * TILE;
     const char* Vt = Vimg + kt * TILE;
-    f32x4 st[RQ][4];
+    f32x4 st[RQ][NJ];
     float mx[RQ];
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) mx[rq] = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (kb + j * 16 < T) {
-        f32x4 a[RQ];
+    for (int j = 0; j < NJ; ++j) {
+      f32x4 a[RQ];
 #pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) a[rq] = zero4();
+      for (int rq = 0; rq < RQ; ++rq) a[rq] = zero4();
 #pragma unroll
-        for (int s = 0; s < DH / 32; ++s) {
-          const bf16x8 kf = frag_rows<DH>(Kt, j * 16, s, l15, lg);
+      for (int s = 0; s < DH / 32; ++s) {
+        const bf16x8 kf = frag_rows<DH>(Kt, j * 16, s, l15, lg);
 #pragma unroll
-          for (int rq = 0; rq < RQ; ++rq) a[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][s], a[rq], 0, 0, 0);
+        for (int rq = 0; rq < RQ; ++rq) a[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[rq][s], a[rq], 0, 0, 0);
+      }
+      // raw scores: the scale rides in the exp2's FMA below (max(c s) = c max(s), c > 0)
+#pragma unroll
+      for (int rq = 0; rq < RQ; ++rq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (EDGE && j == NJ - 1 && kb + j * 16 + lg * 4 + r >= T) a[rq][r] = -INFINITY;
+          mx[rq] = fmaxf(mx[rq], a[rq][r]);
         }
-        // raw scores: the scale rides in the exp2's FMA below (max(c s) = c max(s), c > 0); only a tile that straddles T
-        // needs the per-key validity select
-        const bool edge = kb + j * 16 + 16 > T;
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (edge && kb + j * 16 + lg * 4 + r >= T) a[rq][r] = -INFINITY;
-            mx[rq] = fmaxf(mx[rq], a[rq][r]);
-          }
-          st[rq][j] = a[rq];
-        }
-      } else {
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) st[rq][j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        st[rq][j] = a[rq];
       }
     }
 #pragma unroll
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
       const float mnc = mn * c;
       float ls = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           st[rq][j][r] = fast_exp2(fmaf(st[rq][j][r], c, -mnc));
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
       if (p.drop.thr) {
         const unsigned long long drow = (unsigned long long)bh * T + (q00 + rq * 16 + l15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const unsigned key = kb + j * 16 + lg * 4;
           float k0, k1, k2, k3;
           drop_pair(p.drop, drow, half_cols, key, k0, k1);
@@ -671,21 +671,33 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(AttnArgs p) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (kb + u * 32 < T) {
-        bf16x8 pf[RQ];
+    for (int u = 0; u < (NJ + 1) / 2; ++u) {
+      constexpr bool dummy = false;
+      (void)dummy;
+      const bool two = 2 * u + 1 < NJ;  // compile-time after unrolling
+      bf16x8 pf[RQ];
 #pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) pf[rq] = pack8(st[rq][2 * u], st[rq][2 * u + 1]);
+      for (int rq = 0; rq < RQ; ++rq) pf[rq] = two ? pack8(st[rq][2 * u], st[rq][2 * u + 1 < NJ ? 2 * u + 1 : 2 * u]) : pack8(st[rq][2 * u], zero4());
 #pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) {
-          // a 16-row block with no key in it is not staged: point its half of the fragment at the first block (its P is 0)
-          const bf16x8 vf = frag_cols<DH>(Vt, u * 32, (kb + u * 32 + 16 < T) ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
+      for (int dt = 0; dt < DH / 16; ++dt) {
+        // a 16-row block with no key in it is not staged: point its half of the fragment at the first block (its P is 0)
+        const bf16x8 vf = frag_cols<DH>(Vt, u * 32, two ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
 #pragma unroll
-          for (int rq = 0; rq < RQ; ++rq)
-            ot[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rq], ot[rq][dt], 0, 0, 0);
-        }
+        for (int rq = 0; rq < RQ; ++rq)
+          ot[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[rq], ot[rq][dt], 0, 0, 0);
       }
     }
+  };
+  using std::integral_constant;
+  const int nfull = T / RT;
+  for (int kt = 0; kt < nfull; ++kt) tile(integral_constant<int, 4>{}, integral_constant<bool, false>{}, kt);
+  const int rem = T - nfull * RT;
+  if (rem > 0) {
+    const int nj = (rem + 15) >> 4;
+    if (nj == 1) tile(integral_constant<int, 1>{}, integral_constant<bool, true>{}, nfull);
+    else if (nj == 2) tile(integral_constant<int, 2>{}, integral_constant<bool, true>{}, nfull);
+    else if (nj == 3) tile(integral_constant<int, 3>{}, integral_constant<bool, true>{}, nfull);
+    else tile(integral_constant<int, 4>{}, integral_constant<bool, true>{}, nfull);
   }
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
