@@ -376,6 +376,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
     bv1 = *(const f32x4*)(p.bias + n + 4);
   }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // column sums of the stored (bf16-rounded) values
+  const bool want_cs = p.colsum_part != nullptr;
   u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -476,10 +477,12 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
       }
       u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
       *(u32x4*)(p.C + (m * p.ldc + n) * 2) = pk;
+      if (want_cs) {  // uniform: only the launches that fuse a bias gradient pay the unpack + add per stored vector
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cs[2 * r] += __builtin_bit_cast(float, pk[r] << 16);
-        cs[2 * r + 1] += __builtin_bit_cast(float, pk[r] & 0xFFFF0000u);
+        for (int r = 0; r < 4; ++r) {
+          cs[2 * r] += __builtin_bit_cast(float, pk[r] << 16);
+          cs[2 * r + 1] += __builtin_bit_cast(float, pk[r] & 0xFFFF0000u);
+        }
       }
     }
   }
