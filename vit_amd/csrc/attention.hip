@@ -1464,9 +1464,16 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
       char* cur = QD + (u & 1) * (2 * HALFB);
       char* nxt = QD + ((u + 1) & 1) * (2 * HALFB);
       const bool last_half = half + 1 == nhalves;
-      if (!last_half) issue_half(nxt, bh, half + 1);
-      else if (bh_next < BH) issue_half(nxt, bh_next, 0);
+      auto prefetch_next = [&]() {
+        if (!last_half) issue_half(nxt, bh, half + 1);
+        else if (bh_next < BH) issue_half(nxt, bh_next, 0);
+      };
       const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
+      // The prefetch is issued AFTER the first query pair of phase A (or here, by a wave that has no phase A): the first MFMA of
+      // phase A needs the K / V rows that came by global loads, for which the compiler can only write s_waitcnt vmcnt(0) --
+      // with the LDS-DMA already in flight that wait drained the prefetch it was meant to overlap (369 -> 362 us).
+      const bool in_a = k00 < R && !(p.dbg & 2) && pp0 < pp1;
+      if (!in_a) prefetch_next();
       // ------------------------------------------------------------------ phase A
       if (k00 < R && !(p.dbg & 2)) {
         const float kinf[RQ] = {(k00 + l15 < T) ? 0.f : INFINITY, (k00 + 16 + l15 < T) ? 0.f : INFINITY};
@@ -1533,6 +1540,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
               dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
             }
           }
+          if (pp == pp0) prefetch_next();  // after the first pair: the waits its register operands needed are behind us
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next unit's Q / dO (and a K image issued a unit ago) landed
