@@ -94,3 +94,24 @@ def test_rccl_single_rank_rehearsal(tmp_path, exchange):
     assert torch.equal(plain["grads"][:n], rccl["grads"][:n])
     assert plain["grad_norm"] == rccl["grad_norm"]
     assert torch.equal(plain["params"], rccl["params"])
+
+
+@pytest.mark.parametrize("exchange", ["zero1", "allreduce"])
+def test_checkpoint_resume_under_exchange(tmp_path, exchange):
+    """under 'zero1' every rank holds current AdamW moments only inside its own shard; the checkpoint is written
+    by rank 0 and read by every rank.  A 2-epoch run saved and resumed for a third epoch must end where the uninterrupted
+    3-epoch run ends, on both ranks, bit for bit (parameters and moments) -- which needs the shards gathered before saving."""
+    from vit_amd.launch import launch_ranks
+
+    out = tmp_path / f"resume_{exchange}"
+    out.mkdir()
+    child = os.path.join(ROOT, "tests", "_ddp_resume_child.py")
+    assert launch_ranks(2, child, [str(out), exchange], extra_env={"VIT_DIST_BACKEND": "gloo"}) == 0
+    r = [torch.load(out / f"rank{k}.pt", weights_only=True) for k in range(2)]
+    assert r[0]["full"]["mode"] == exchange and r[0]["full"]["step"] == r[0]["resumed"]["step"] == 6
+    for k in range(2):
+        for name in ("params", "m", "v"):
+            assert torch.equal(r[k]["full"][name], r[k]["resumed"][name]), (k, name)
+    assert torch.equal(r[0]["full"]["params"], r[1]["full"]["params"])
+    # the saved moments themselves were complete (rank 0's file): nothing of the other rank's shard left at zero
+    assert float((r[0]["part"]["m"] != 0).float().mean()) > 0.9

@@ -362,7 +362,7 @@ def test_hip_graph_step_equals_eager(dev, precision):
         finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()},
                         trainer.optimizer._step, float(trainer.optimizer.last_grad_norm))
         if mode == "graph":
-            assert isinstance(trainer._graphed, GraphedTrainStep)
+            assert len(trainer._graphed) == 1 and all(isinstance(g, GraphedTrainStep) for g in trainer._graphed.values())
     assert finals["eager"][0] == finals["graph"][0], (finals["eager"][0], finals["graph"][0])
     assert finals["eager"][2] == finals["graph"][2] == 4
     assert finals["eager"][3] == finals["graph"][3]
@@ -377,6 +377,94 @@ def test_hip_graph_step_equals_eager(dev, precision):
     b = tuple(t.cuda() for t in batches[0])
     seen = {round(float(trainer.training_step(module, b, i)), 7) for i in range(4)}
     assert len(seen) == 4, seen
+
+
+@pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
+def test_hip_graph_survives_validation_and_shape_changes(dev, precision):
+    """a validation pass (another arena: need_grad = False), a partial last batch (another batch shape)
+    and a workspace re-allocation between replays must not leave the captured graph on freed memory: the run replay ->
+    validate -> replay (short batch) -> grow the workspace -> replay equals the eager run bit for bit, and the graph of the
+    full batch is NOT re-captured on the way (same object, same arena tensors held)."""
+    from vit_amd import _cabi
+
+    batches = list(Batches(40, 5))  # 16, 16, 8
+    val = Batches(24, 6, four=True)
+    finals = {}
+    for mode in ("eager", "graph"):
+        cfg = c1_config(precision=precision, hip_graph=(mode == "graph"))
+        module, trainer = make(cfg)
+        module.model.config.hidden_dropout_prob = 0.0
+        module.model.config.attention_probs_dropout_prob = 0.0
+        trainer._setup(module)
+        module.train()
+        losses, first = [], None
+        for rnd in range(2):
+            for i, b in enumerate(batches):
+                losses.append(float(trainer.training_step(module, tuple(t.cuda() for t in b), i)))
+                if mode == "graph" and first is None:
+                    first = next(iter(trainer._graphed.values()))
+                    held = [t.data_ptr() for t in first._held[1].values() if torch.is_tensor(t)]
+            logs = trainer.validate(module, val)  # evaluation forward between replays
+            losses.append(logs["val_mae"])
+            h = _cabi.handle_for(torch.device("cuda", 0))
+            h.set_workspace(h.workspace_bytes + (1 << 20))  # the handle moves to another workspace allocation
+            torch.cuda.empty_cache()
+            junk = torch.full((64 << 20,), float("nan"), device="cuda")  # whatever was freed gets poisoned
+            del junk
+        finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in module.model.state_dict().items()})
+        if mode == "graph":
+            assert len(trainer._graphed) == 2 and next(iter(trainer._graphed.values())) is first
+            assert held == [t.data_ptr() for t in first._held[1].values() if torch.is_tensor(t)]
+            assert trainer.use_graph
+    assert finals["eager"][0] == finals["graph"][0], (finals["eager"][0], finals["graph"][0])
+    for k in finals["eager"][1]:
+        assert torch.equal(finals["eager"][1][k], finals["graph"][1][k]), k
+
+
+def test_hip_graph_replay_rezeroes_dlast(dev):
+    """`d last_hidden` is zero-filled by a kernel inside the captured step (a hipMemsetAsync node was observed
+    not to run before its consumers).  Poison the buffer with NaN before a replay: the replay must still produce finite
+    gradients equal to the eager step's."""
+    cfg = c1_config(precision="bf16-mixed", hip_graph=True)
+    module, trainer = make(cfg)
+    module.model.config.hidden_dropout_prob = 0.0
+    module.model.config.attention_probs_dropout_prob = 0.0
+    trainer._setup(module)
+    module.train()
+    b = tuple(t.cuda() for t in next(iter(Batches(16, 5))))
+    trainer.training_step(module, b, 0)
+    g = next(iter(trainer._graphed.values()))
+    eng = module.model.engine
+    for _ in range(3):
+        g._held[1]["dlast"].fill_(float("nan"))
+        trainer.training_step(module, b, 0)
+        assert torch.isfinite(eng.grads[:eng.layout.n_trainable]).all()
+        assert torch.isfinite(trainer.optimizer.last_grad_norm).all()
+    cfg2 = c1_config(precision="bf16-mixed")
+    module2, trainer2 = make(cfg2)
+    module2.model.config.hidden_dropout_prob = 0.0
+    module2.model.config.attention_probs_dropout_prob = 0.0
+    trainer2._setup(module2)
+    module2.train()
+    for _ in range(4):
+        trainer2.training_step(module2, b, 0)
+    for (k, v), (_, w) in zip(module.model.state_dict().items(), module2.model.state_dict().items()):
+        assert torch.equal(v, w), k
+
+
+def test_hip_graph_falls_back_to_eager_with_noise(dev):
+    """a configuration the capture cannot take (on-the-fly noise) trains eagerly with one warning instead of
+    raising out of fit()."""
+    cfg = c1_config(precision="bf16-mixed", hip_graph=True)
+    cfg["noise"] = {"noise_level": 0.5}
+    module, trainer = make(cfg)
+    trainer._setup(module)
+    module.train()
+    b = tuple(t.cuda() for t in next(iter(Batches(16, 5))))
+    with pytest.warns(UserWarning, match="eager"):
+        l0 = float(trainer.training_step(module, b, 0))
+    assert not trainer.use_graph and np.isfinite(l0)
+    assert np.isfinite(float(trainer.training_step(module, b, 1)))
 
 
 def test_cli_run_save_then_test_only(dev, tmp_path):

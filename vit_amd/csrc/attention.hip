@@ -44,9 +44,20 @@ struct AttnArgs {
   float* csum_part;  // resident backward kernels: [B * nsplit * wpw][3 * H * dh] per-wave column sums of dqkv as stored, or NULL
 };
 
+// XOR applied to the 16-byte chunk index of row r.  Two kinds of read share an image and both must be free of bank conflicts
+// (r03: the earlier swizzles served the row reads only; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE read 0.27 / 0.43 in the
+// forward / backward kernels while the GEMM images read 0.00):
+//  * row fragments, ds_read_b128: a 16-lane group = 8 rows of lane group lg at chunk c0 and 8 rows of lg ^ 1 at chunk c0 ^ 1
+//    (rows r and r ^ 8 never share a chunk) -> the 16 (row, chunk) slots must tile the 256-byte bank row;
+//  * transposed fragments, ds_read_b64_tr_b16: a 32-lane half = 8 consecutive rows x one 32-byte chunk PAIR {2dt, 2dt + 1}
+//    -> the 8 rows must land on 8 different 32-byte regions of the bank row, so the pair index (chunk >> 1) has to be
+//    XORed with something that differs between rows that share their position (r mod rows-per-bank-row).
+// DH = 64 (128-byte rows, 2 per bank row): (r & 6) -- pair index ^ ((r >> 1) & 3), the row's parity picks the half.
+// DH = 32 (64-byte rows, 4 per bank row): rows r and r + 4 share a quarter -> pair index ^ ((r >> 2) & 1).
+// DH = 128 (256-byte rows): pair index ^ (r & 7).
 template <int DH>
 __device__ __forceinline__ int swz(int r) {
-  return DH == 32 ? ((r >> 2) & 3) : (DH == 64 ? ((r >> 1) & 7) : (r & 15));
+  return DH == 32 ? ((r >> 1) & 2) : (DH == 64 ? (r & 6) : ((r & 7) << 1));
 }
 template <int DH>
 __device__ __forceinline__ int tile_off(int r, int c) {
@@ -1057,7 +1068,16 @@ __device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, const u32x
   }
 }
 
-constexpr int DSP = 288;  // bytes per key row of the dS image: 128 queries x 2 B + 32 (4 consecutive rows hit disjoint banks)
+// dS image of the fused backward kernels: [key][128 queries] bf16, 256 bytes per key row, the 8-byte slot (4 consecutive
+// queries of one key: what a phase-A lane stores and a phase-B lane's transposing read fetches) XOR-swizzled by the key:
+//  * phase-A store (ds_write_b64, banks mod 32, 16-lane groups = 16 consecutive keys at ONE slot): slot ^ x must differ
+//    mod 16 between the 16 keys -> x mod 16 = a bijection of key & 15;
+//  * phase-B read (ds_read_b64_tr_b16, banks mod 64, a 32-lane half = 8 consecutive keys x 4 adjacent slots): the
+//    32-byte group index (slot >> 2) ^ (x >> 2) must differ between the 8 keys -> x >> 2 = key & 7.
+// x = ((key & 7) << 2) | ((key >> 2) & 3) does both (r03; the padded 288-byte rows before it stored 4-way conflicted).
+constexpr int DSP = 256;
+__device__ __forceinline__ int ds_swz(int key) { return ((key & 7) << 2) | ((key >> 2) & 3); }
+__device__ __forceinline__ int ds_off(int key, int slot) { return key * DSP + ((slot ^ ds_swz(key)) << 3); }
 
 template <int DH>
 __device__ __forceinline__ void load_all_tiles3(char* imgA, const short* ga, long lda, char* imgB, const short* gb, long ldb,
@@ -1223,7 +1243,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
               pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
               dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
               if (k00 + rq * 16 < R)  // [key][query of the half]: 4 consecutive queries of this lane's key
-                *(u32x2*)(dSimg + (k00 + rq * 16 + l15) * DSP + (q0 - pp0 * 32 + lg * 4) * 2) = dsh[rq][jj];
+                *(u32x2*)(dSimg + ds_off(k00 + rq * 16 + l15, ((q0 - pp0 * 32) >> 2) + lg)) = dsh[rq][jj];
             }
           }
         }
@@ -1254,13 +1274,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
 #pragma unroll
       for (int i = 0; i < DPW; ++i) dqt[i] = zero4();
       const int tq = l15 >> 2, tp = l15 & 3;
-      const char* dcol = dSimg + ((wave / WPQ) * 16 + 4 * tp) * 2;
+      // keys kb + 4 lg + tq (+ 16): the swizzle term depends on key & 15 only, so it is one constant per lane
+      const char* dcol = dSimg + ds_off(4 * lg + tq, (wave / WPQ) * 4 + tp);
       for (int ks = 0; ks < nks; ++ks) {
         const int kb = ks * 32;
         const bool hi_ok = kb + 16 < R;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 4 * lg + tq) * DSP));
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + kb * DSP));
         bf16x4 hi = {0, 0, 0, 0};
-        if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16 + 4 * lg + tq) * DSP));
+        if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16) * DSP));
         const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const char* Kt = Kimg + (kb >> 6) * TILE;
         const int r0 = kb & 63;
@@ -1520,7 +1541,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
                 pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
                 dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
                 if (k00 + rq * 16 < R)
-                  *(u32x2*)(dSimg + (k00 + rq * 16 + l15) * DSP + (ql + jj * 16 + lg * 4) * 2) = dsh[rq][jj];
+                  *(u32x2*)(dSimg + ds_off(k00 + rq * 16 + l15, (ql >> 2) + jj * 4 + lg)) = dsh[rq][jj];
               }
             }
           }
@@ -1558,13 +1579,13 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
         const bool have = qt < nq && qt < pp1 * 2 && !(p.dbg & 1);
         if (have) {
           const int tq = l15 >> 2, tp = l15 & 3;
-          const char* dcol = dSimg + (wave * 16 + 4 * tp) * 2;
+          const char* dcol = dSimg + ds_off(4 * lg + tq, wave * 4 + tp);
           for (int ks = 0; ks < nks; ++ks) {
             const int kb = ks * 32;
             const bool hi_ok = kb + 16 < R;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 4 * lg + tq) * DSP));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + kb * DSP));
             bf16x4 hi = {0, 0, 0, 0};
-            if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16 + 4 * lg + tq) * DSP));
+            if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16) * DSP));
             const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const char* Kt = Kimg + (kb >> 6) * TILE;
             const int r0 = kb & 63;

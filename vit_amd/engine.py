@@ -143,6 +143,7 @@ class ViTEngine:
         self.grads: Optional[torch.Tensor] = None
         self._shadow_version = -1
         self._arena_key = None
+        self._arenas: Dict[bool, tuple] = {}  # train? -> (key, act, tmp, Mp): one arena for training, one for evaluation
         self.act: Dict[str, object] = {}
         self.tmp: Dict[str, torch.Tensor] = {}
         self.precision = "f32"       # 'f32' (reference default precision='32') | 'bf16' (precision='bf16-mixed')
@@ -178,8 +179,7 @@ class ViTEngine:
             raise ValueError(f"Unsupported precision '{precision}'")
         if mode != self.precision:
             self.precision = mode
-            self._arena_key = None
-            self.act, self.tmp = {}, {}
+            self._drop_arenas()
         return mode
 
     @property
@@ -199,8 +199,7 @@ class ViTEngine:
         self.shadow = None
         self.grads = None
         self._shadow_version = -1
-        self._arena_key = None
-        self.act, self.tmp = {}, {}
+        self._drop_arenas()
 
     def p(self, name: str) -> torch.Tensor:
         return self.layout.view(self.flat, name)
@@ -249,9 +248,19 @@ class ViTEngine:
 
     # ------------------------------------------------------------------ arena
     def _ensure_arena(self, B: int, train: bool):
+        """Select (allocating on first use) the activation arena for this batch size.  Training and evaluation forwards keep
+        SEPARATE arenas (one slot each): a validation pass between two optimisation steps must not release the training
+        arena -- a captured hipGraph (vit_amd/graph.py) replays raw pointers into it, and re-allocating 17 GB per epoch would
+        be waste in any case.  A slot is replaced when its batch size or the precision changes."""
         key = (B, train, self.precision)
         if self._arena_key == key:
             return
+        slot = self._arenas.get(train)
+        if slot is not None and slot[0] == key:
+            self._arena_key, self.act, self.tmp, self._Mp = key, slot[1], slot[2], slot[3]
+            return
+        self.act, self.tmp = {}, {}
+        self._arenas.pop(train, None)  # release the slot's old tensors before allocating their replacement
         c = self.cfg
         dev = self.flat.device
         T, D, Fd, H, L, N, P = c.seq_len, c.hidden_size, c.intermediate_size, c.num_attention_heads, \
@@ -295,6 +304,12 @@ class ViTEngine:
                 dlast=E((B, T, D), f32),
             )
         self._arena_key = key
+        self._arenas[train] = (key, self.act, self.tmp, Mp)
+
+    def _drop_arenas(self):
+        self._arena_key = None
+        self._arenas = {}
+        self.act, self.tmp = {}, {}
 
     def _rope_tables(self, T: int):
         """Half-width cos / sin tables of RotaryPositionEmbedding (rope.py:36-56), computed on the host by the reference's

@@ -68,7 +68,9 @@ class GraphedTrainStep:
         keep = (eng.flat.clone(), optimizer._m.clone(), optimizer._v.clone(), int(optimizer._step), int(eng.step_counter))
         # warm-up on a side stream (torch's capture protocol): sizes the arena / workspace, sets the kernels' LDS attributes
         # one stream inside the graph: two-branch graphs (the weight-gradient GEMMs on their second stream) replayed 0.7 ms per
-        # step SLOWER than the same two streams launched eagerly on this stack
+        # step SLOWER than the same two streams launched eagerly on this stack.  The engine's own setting is put back after
+        # the capture, so eager steps elsewhere (another batch shape, the bench's instrumented repetition) keep theirs.
+        overlap_was = eng.overlap_dw
         eng.overlap_dw = False
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -81,15 +83,22 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.loss = self._body()
+            # The graph replays RAW POINTERS into the activation arena and the library workspace.  Hold the tensors: whatever
+            # the engine or the handle do later (another batch size, a grown workspace), the captured addresses stay valid and
+            # are nobody else's.  (The engine also keeps evaluation forwards in their own arena: engine._ensure_arena.)
+            self._held = (eng.act, eng.tmp, self.h._ws)
         finally:
+            # also on a failed warm-up / capture: the warm-up steps were real optimisation steps and must not leak into the run
             _cabi.check(self.h.lib.vit_step_state_bind(self.h.h, None), "vit_step_state_bind")
-        eng.flat.copy_(keep[0]); optimizer._m.copy_(keep[1]); optimizer._v.copy_(keep[2])
-        optimizer._step, eng.step_counter = keep[3], keep[4]
-        self.state[5] = keep[3]
-        if eng.shadow is not None:
-            vf.cast_f32_bf16(eng.flat, eng.shadow)
-        eng.mark_shadow_fresh()
-        torch.cuda.synchronize(dev)
+            eng.overlap_dw = overlap_was
+            torch.cuda.synchronize(dev)
+            eng.flat.copy_(keep[0]); optimizer._m.copy_(keep[1]); optimizer._v.copy_(keep[2])
+            optimizer._step, eng.step_counter = keep[3], keep[4]
+            self.state[5] = keep[3]
+            if eng.shadow is not None:
+                vf.cast_f32_bf16(eng.flat, eng.shadow)
+            eng.mark_shadow_fresh()
+            torch.cuda.synchronize(dev)
 
     def _set_lr(self, lr: float):
         if lr != self._lr:

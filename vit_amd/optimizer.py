@@ -165,6 +165,17 @@ class FusedAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=True)
 
+    def gather_sharded_state(self):
+        """Under the 'zero1' exchange a rank's moment buffers are current only inside its own shard of every sharded bucket.
+        A checkpoint is written by rank 0 and read back by EVERY rank, so before `state_dict()` the shards are all-gathered
+        into every rank's buffers (a collective: all ranks must call this; a no-op for the all-reduce exchange and for a
+        single process).  Without it the other ranks resumed with zero moments (first update ~3x lr; ADVICE r2 #2)."""
+        red = self._reducer
+        if red is None or getattr(red, "mode", "") != "zero1" or self._m is None or self._step == 0:
+            return
+        red.all_gather_params(self._m)
+        red.all_gather_params(self._v)
+
     # ------------------------------------------------------------------ torch.optim.AdamW-format state
     def state_dict(self):
         lay = self.model.engine.layout

@@ -87,6 +87,8 @@ class Checkpointer:
         return v > self.best_score if self.mode == "max" else v < self.best_score
 
     def after_validation(self, trainer: "Trainer", module, logs: Dict[str, float]):
+        if hasattr(trainer.optimizer, "gather_sharded_state"):
+            trainer.optimizer.gather_sharded_state()  # 'zero1': a collective, so before the rank check
         if trainer.rank != 0:
             return
         os.makedirs(self.dirpath, exist_ok=True)
@@ -272,11 +274,27 @@ class Trainer:
         return loss
 
     def _graph_step(self, module, batch):
+        """One captured graph per (batch shape, precision), at most two kept (the full batch and an epoch's partial last
+        batch; each holds its own activation arena).  What the capture cannot take -- another optimizer, a trainable input
+        preprocessor, on-the-fly noise -- falls back to eager launches for the rest of the run, with one warning."""
         from .graph import GraphedTrainStep
 
-        g = self._graphed
-        if g is None or g.x.shape != batch[0].shape or g.eng.precision != module.model.engine.precision:
-            g = self._graphed = GraphedTrainStep(module, self.optimizer, batch)  # capture (runs warm-up steps on this batch)
+        key = (tuple(batch[0].shape), module.model.engine.precision)
+        if self._graphed is None:
+            self._graphed = {}
+        g = self._graphed.get(key)
+        if g is None:
+            try:
+                g = GraphedTrainStep(module, self.optimizer, batch)  # capture (runs warm-up steps on this batch)
+            except (TypeError, ValueError) as e:
+                import warnings
+
+                warnings.warn(f"train.hip_graph: {e}; continuing with eager launches")
+                self.use_graph = False
+                return self.training_step(module, batch, 0)
+            while len(self._graphed) >= 2:
+                self._graphed.pop(next(iter(self._graphed)))
+            self._graphed[key] = g
         loss = g.step(batch)
         module.log(f"{module.loss_name}_loss", loss, on_step=True, on_epoch=True, prog_bar=True)
         if self.sched_cfg and self.sched_cfg.get("interval") == "step":
@@ -332,6 +350,8 @@ class Trainer:
         sch = self.sched_cfg["scheduler"].state_dict() if self.sched_cfg else None
         return {
             "epoch": int(self.current_epoch), "global_step": int(self.global_step), "state_dict": sd,
+            # Lightning's loader reads this key to decide on checkpoint migrations; the reference pins lightning 2.5.4 (requirements.txt:23)
+            "pytorch-lightning_version": "2.5.4",
             "optimizer_states": [self.optimizer.state_dict()] if self.optimizer is not None else [],
             "lr_schedulers": [_plain(sch)] if sch is not None else [],
             "callbacks": {"early_stopping": {"best_score": self._es_best, "wait_count": int(self._es_bad)}},
