@@ -11,7 +11,8 @@ A "step" is one full optimisation step of the reference's `training_step` path o
 resident in HBM: forward (dropout on) -> backward -> [RCCL gradient all-reduce, overlapped] -> global-norm clip 0.5 ->
 AdamW.  Workload = SURVEY.md section 8 config C3: flux [256, 50176] f32 per GPU (a 224x224x1 image flattened),
 patch 256 (=16^2) -> 196 tokens + CLS, hidden 768, 12 heads, 12 layers, MLP 3072, 85.8 M parameters, regression head,
-MSE loss (what baseline.yaml's loss.name 'mae' resolves to), AdamW lr 1e-3 wd 0.  Weak scaling: 256 images per GPU.
+MSE loss (what baseline.yaml's loss.name 'mae' resolves to), AdamW lr 1e-3 wd 0.  Weak scaling: 256 images per GPU
+(default; `--global-batch 256` fixes the total instead: strong scaling, 256 / N images per GPU).
 
 Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
   roofline     -- the dominant kernel (by summed time) of the step: algorithmic FLOPs per launch / mean launch duration,
@@ -122,6 +123,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: this many images per step over ALL GPUs (per-GPU batch = global / N; SURVEY.md section "
+                         "8d: 'also report fixed-global-256 strong scaling'); the JSON line then says \"scaling\": \"strong\"")
     ap.add_argument("--precision", default="bf16-mixed", choices=["bf16-mixed", "32"],
                     help="bf16-mixed = the BASELINE.json metric; 32 = the fp32-class mode (x3 GEMMs), for the record only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +171,10 @@ def main():
     L, P, D, layers, heads, B = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
+        B = args.global_batch // world
     config = {
         "model": dict(name="vit", task_type="reg", image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
                       num_attention_heads=heads, stride_size=P, proj_fn="SW"),
@@ -338,7 +346,8 @@ def main():
         out = {
             "metric": "images/sec ViT-B/16 224^2 bf16 train step" if args.workload == "vit_b16_224" else f"images/sec {args.workload} bf16 train step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+            "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16-mixed" else "f32 (split-bf16 x3 MFMA)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",

@@ -254,6 +254,9 @@ int vit_colsum(vit_handle h, const void* a, int a_dtype, int64_t lda, float* out
                vit_stream stream);
 /* f32 -> bf16 copy (weights after an optimizer step, inputs) */
 int vit_cast_f32_bf16(vit_handle h, const float* src, void* dst, int64_t n, vit_stream stream);
+/* dst (f32) = scale * src (bf16): the receive side of the optional bf16 gradient exchange (`train.ddp_grad_dtype: bf16`;
+ * the reference's DDP exchanges fp32 gradients, src/hardware_utils.py:86-95 -- SURVEY.md section 5 prices the halved bytes) */
+int vit_cast_bf16_f32(vit_handle h, const void* src, float* dst, int64_t n, float scale, vit_stream stream);
 
 /* ------------------------------------------------------------------------------------- Head + loss
  * logits[B, C] = cls_rows * W^T + b, cls_rows = last_hidden[:, 0, :] (specvit.py:78-81); loss (specvit.py:83-89):

@@ -2,8 +2,11 @@
 """`scripts/run.py` of the reference (scripts/run.py:14-54) on the MI355X path: same arguments (-f/--config, -w, --save,
 -g, --debug, --ckpt, --seed), same seeding and config plumbing, `Experiment(...).run()` replaced by the build's module +
 trainer.  `--save` keeps the best-by-monitor checkpoint and `last.ckpt` under $CKPT_DIR (vit.py:386-414); `--ckpt` resumes
-(vit.py:464); `-g N` starts N rank processes itself.  The reference's HDF5 datasets are out of scope (SURVEY.md section 2
-#10), so data comes from `--synthetic N` seeded spectra with the reference's batch contract (flux, error, labels)."""
+(vit.py:464); `-g N` starts N rank processes itself (no `-g`: every visible GPU, as the reference does, run.py:35-38).
+Data: `data.file_path` / `val_path` / `test_path` of the config through `vit_amd.data.SpecDataModule` (the reference's
+`ViTDataModule.from_config`, vit.py:29-50: `.npz` files here, the reference's HDF5 layout when h5py imports; training-split
+label statistics re-used on val / test).  `--synthetic N` is the explicit fallback: N seeded spectra with the same batch
+contract (flux, error, labels) instead of files."""
 import argparse
 import os
 import sys
@@ -26,7 +29,8 @@ def parse_args():
     p.add_argument("--debug", type=int, default=0)
     p.add_argument("--ckpt", type=str, default=None)
     p.add_argument("--seed", type=int, default=42)
-    p.add_argument("--synthetic", type=int, default=4096, help="number of synthetic training spectra")
+    p.add_argument("--synthetic", type=int, default=None,
+                   help="train on N seeded synthetic spectra instead of the files named in the config's data section")
     return p.parse_args()
 
 
@@ -62,32 +66,68 @@ class SyntheticSpectra:
             yield self.flux[j], self.error[j], self.labels[j]
 
 
+def visible_gpus() -> int:
+    """Devices this process may use, WITHOUT initialising HIP (the launcher parent must never touch the GPU: a process that
+    has cannot start rank processes safely on this pool).  torch.cuda.device_count() only enumerates on this stack."""
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+class DataSource:
+    """The three loaders of a run: from the config's files (SpecDataModule) or, with --synthetic N, seeded spectra."""
+
+    def __init__(self, args, config, module):
+        from vit_amd.data import SpecDataModule
+
+        self.synthetic = getattr(args, "synthetic", None)
+        self.config, self.module = config, module
+        self.dm = None
+        if self.synthetic is None:
+            self.dm = SpecDataModule.from_config(config)
+            if not self.dm.paths["train"] and not self.dm.paths["test"]:
+                raise SystemExit("the config names no data files (data.file_path / val_path / test_path); "
+                                 "pass --synthetic N to run on seeded synthetic spectra")
+        m, train = config["model"], config["train"]
+        self._syn = lambda n, seed, shuffle: SyntheticSpectra(n, m["image_size"], train.get("batch_size", 64), m["task_type"],
+                                                              module.model.config.num_labels, seed, shuffle)
+
+    def fit_loaders(self, debug):
+        if self.dm is None:
+            n_eval = max(self.config["train"].get("batch_size", 64), self.synthetic // 8)
+            return self._syn(self.synthetic, 1, not debug), self._syn(n_eval, 2, False)
+        self.dm.setup("fit")
+        return self.dm.train_dataloader(), self.dm.val_dataloader()
+
+    def test_loader(self):
+        if self.dm is None:
+            n_eval = max(self.config["train"].get("batch_size", 64), self.synthetic // 8)
+            return self._syn(n_eval, 3, False)
+        self.dm.setup("test")
+        return self.dm.test_dataloader()
+
+
 def build(args, for_test=False):
     seed_everything(args.seed)
     config = load_config(args.config)
     if args.gpu is None:
-        args.gpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        args.gpu = visible_gpus()
     train = config.setdefault("train", {})
     train["gpus"] = args.gpu
     train["debug"] = args.debug
     train["save"] = False if for_test else bool(getattr(args, "save", False))  # pure evaluation never saves (test.py:41)
     module = ViTLModule(config=config)
-    m = config["model"]
-    bs = train.get("batch_size", 64)
-
-    def spectra(n, seed, shuffle):
-        return SyntheticSpectra(n, m["image_size"], bs, m["task_type"], module.model.config.num_labels, seed, shuffle)
-
-    return config, module, spectra
+    return config, module, DataSource(args, config, module)
 
 
 def main(args):
     """`launch.sh run`: fit (optionally resuming from --ckpt: weights, optimizer, scheduler, epoch), then test."""
-    config, module, spectra = build(args)
-    n_eval = max(config["train"].get("batch_size", 64), args.synthetic // 8)
+    config, module, data = build(args)
     trainer = Trainer(config["train"])
-    hist = trainer.fit(module, spectra(args.synthetic, 1, not args.debug), spectra(n_eval, 2, False), ckpt_path=args.ckpt)
-    test_logs = trainer.test(module, spectra(n_eval, 3, False))
+    train_loader, val_loader = data.fit_loaders(args.debug)
+    hist = trainer.fit(module, train_loader, val_loader, ckpt_path=args.ckpt)
+    test_logs = trainer.test(module, data.test_loader())
     if trainer.rank == 0:
         print("[test] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(test_logs.items())))
         if trainer.checkpointer is not None:
@@ -100,6 +140,9 @@ if __name__ == "__main__":
     a = parse_args()
     from vit_amd.launch import launch_ranks, under_launcher
 
-    if a.gpu and a.gpu > 1 and not under_launcher():  # one command -> N ranks (hardware_utils.py:86-95 'ddp')
-        sys.exit(launch_ranks(a.gpu, os.path.abspath(__file__), sys.argv[1:]))
+    if not under_launcher():  # one command -> N ranks (hardware_utils.py:86-95 'ddp'); no -g: all visible GPUs (run.py:35-38)
+        n = a.gpu if a.gpu is not None else visible_gpus()
+        if n and n > 1:
+            argv = sys.argv[1:] if a.gpu is not None else sys.argv[1:] + ["-g", str(n)]
+            sys.exit(launch_ranks(n, os.path.abspath(__file__), argv))
     main(a)

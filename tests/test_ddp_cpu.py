@@ -64,6 +64,24 @@ def _worker(rank, world, port, q):
         flat2[a:b] = torch.arange(lay.n_total, dtype=torch.float32)[a:b] + 1.0  # "updated" only where this rank owns
     z.all_gather_params(flat2)
     ok = ok and torch.equal(flat2[:n], torch.arange(lay.n_total, dtype=torch.float32)[:n] + 1.0)
+    # optional bf16 exchange (train.ddp_grad_dtype): half the bytes, the mean carries bf16 rounding (and nothing worse), the
+    # fp32 buffer outside the buckets is untouched, zero1 refuses it
+    gens = [torch.Generator().manual_seed(5 + k) for k in range(world)]
+    locals_ = [torch.randn(lay.n_total, generator=gn) for gn in gens]
+    gb = locals_[rank].clone()
+    redb = d.GradAllReducer(lambda: gb, lay.buckets(), max_bucket_elems=1000, grad_dtype="bf16")
+    for lo, hi in lay.buckets():
+        redb.bucket_ready(lo, hi)
+    redb.finish()
+    exact = sum(locals_) / world
+    err = float((gb[:n] - exact[:n]).norm() / exact[:n].norm())
+    ok = ok and 1e-4 < err < 6e-3 and torch.equal(gb[n:], locals_[rank][n:])
+    ok = ok and redb.bytes_per_step * 2 == red.bytes_per_step and redb.calls_per_step == red.calls_per_step
+    try:
+        d.ShardedGradReducer(lambda: gb, lay.buckets(), grad_dtype="bf16")
+        ok = False
+    except ValueError:
+        pass
     idx = d.shard_indices(11, rank, world, epoch=3, shuffle=True, seed=42)
     q.put((rank, bool(ok), idx.tolist(), red.bytes_reduced))
     dist.barrier()

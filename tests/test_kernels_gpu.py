@@ -725,7 +725,8 @@ def test_attention_delta_residual(dev, B, H, T, dh):
 
 
 @pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 197, 64), (1, 2, 224, 64), (1, 2, 240, 32), (3, 1, 17, 64), (1, 2, 64, 64),
-                                      (40, 12, 197, 64), (300, 1, 130, 64)])  # the last two: several heads per persistent workgroup
+                                      (40, 12, 197, 64), (300, 1, 130, 64), (2, 3, 208, 64), (3, 2, 65, 64), (2, 2, 96, 64),
+                                      (64, 5, 177, 64)])  # (40, 12, ..), (300, 1, ..), (64, 5, ..): several heads per persistent workgroup
 @pytest.mark.parametrize("drop", [(0.0, 0, 0), (0.1, 7, 5)])
 def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     """The single-kernel backward (one workgroup per head; dS through the LDS) against the dQ + dK/dV pair: same dropout
@@ -741,16 +742,18 @@ def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     dctx = bf(randn((B * T, H * dh), dev, 71))
     out = {}
     try:
-        for fused in (0, 1, 2, 3):  # two-kernel path, fused with 8 / 16 waves, persistent pipelined form (dh = 64, T <= 224)
+        # two-kernel path, fused with 8 / 16 waves, persistent form (dh = 64, T <= 224), pair-pipelined form (dh 64, 64 <= T <= 208;
+        # elsewhere 4 falls through to 3 / 1)
+        for fused in (0, 1, 2, 3, 4):
             _cabi.set_option("attn_bwd_fused", fused)
             cs = torch.zeros(3 * H * dh, device=dev)
             delta = torch.zeros((B * H, T), device=dev)
             d = vf.attention_bwd(qkv, ctx, dctx, lse, B, H, T, dh, scale, dropout=drop, colsum_out=cs, ctx_lo=lo, delta=delta)
             out[fused] = (d.clone(), cs.clone(), delta.clone())
     finally:
-        _cabi.set_option("attn_bwd_fused", 3)
+        _cabi.set_option("attn_bwd_fused", 4)
     a, b_ = out[0], out[1]
-    for k in (2, 3):
+    for k in (2, 3, 4):
         assert rel(out[k][0], a[0]) < 6e-3 and rel(out[k][2], a[2]) < 1e-5, k
         assert rel(out[k][1], out[k][0].float().sum(0)) < 1e-5, k
     assert rel(b_[0], a[0]) < 6e-3, rel(b_[0], a[0])

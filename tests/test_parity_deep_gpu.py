@@ -109,7 +109,8 @@ def test_deep_eval_forward(dev, tag, precision):
     else:
         assert max(errs) < 1.5e-2 and e_rows < 1.5e-2 and max(nrm) < 5e-3, (errs, e_rows, nrm)
         assert e_att < 2e-2 and e_arow < 2e-2, (e_att, e_arow)
-        assert max(e_logits, e_fix_logits) <= 1.5 * e_ref_bf16 + 1e-3, (e_logits, e_fix_logits, e_ref_bf16)
+        # measured 0.63-0.82 x the reference's own bf16-autocast error; the gate sits just above 1 x
+        assert max(e_logits, e_fix_logits) <= 1.15 * e_ref_bf16 + 1e-3, (e_logits, e_fix_logits, e_ref_bf16)
         # MSE: d(loss) ~ 2 residual d(logit); bound the loss through the measured logit error
         lg = torch.from_numpy(g["logits"]).double().flatten()
         floor = 4.0 * o["loss"] ** 0.5 * e_logits * float(lg.pow(2).mean().sqrt())
@@ -123,7 +124,7 @@ def _check_grads(model, o, precision, tag):
     tol, tol_cos = (2e-4, 1 - 1e-7) if precision == "32" else (4e-2, 0.999)
     ref_bf16 = float(np.max(o["ref_bf16_grad_err"]))
     if precision != "32":
-        tol = 1.5 * ref_bf16 + 2e-3
+        tol = 1.15 * ref_bf16 + 1e-3  # measured 0.85 (C3) / 0.99 (C5) x the reference's WORST bf16 gradient error
     gmax = max(float(v.norm()) for v in o["grads"].values() if v is not None)
     for name, p in model.named_parameters():
         ref = o["grads"][name]

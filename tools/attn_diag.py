@@ -33,4 +33,4 @@ for fused in (1, 3):
         _cabi.set_option("attn_debug", 0)
         print(f"mode{fused} dropout {dp[0]}: " + "  ".join(f"dbg{d}={v:.0f}" for d, v in row), flush=True)
 print("dbg bits: 1 = no phase B, 2 = no phase A, 4 = no Q/dO/K staging, 8 = no dK/dV stores")
-_cabi.set_option("attn_bwd_fused", 3)
+_cabi.set_option("attn_bwd_fused", 4)

@@ -82,6 +82,7 @@ _PROTOS = {
     "vit_dropout_bwd_cast": [_P, _P, _P, _I, _I, _I, _F, _U64, _U64, _P],
     "vit_colsum": [_P, _P, _I, _I64, _P, _I, _I, _I, _P],
     "vit_cast_f32_bf16": [_P, _P, _P, _I64, _P],
+    "vit_cast_bf16_f32": [_P, _P, _P, _I64, _F, _P],
     "vit_head_loss_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vit_head_loss_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vit_grad_sqnorm": [_P, _P, _I64, _P, _P],

@@ -10,6 +10,7 @@ struct vit_ctx {
   void* ws;
   size_t ws_bytes;
   const void* step_state;  // device memory: vit::StepState, or NULL (vit_step_state_bind)
+  int num_cus;             // compute units of the device (read once in vit_create): grid size of the persistent kernels
 };
 
 namespace vit {
@@ -28,6 +29,20 @@ void set_error(const char* fmt, ...) {
 }
 
 const StepState* ctx_step_state(vit_handle h) { return h ? (const StepState*)h->step_state : nullptr; }
+
+int ctx_num_cus(vit_handle h) {
+  // without a handle (kernel-level calls of the C ABI that pass NULL): the current device, asked once
+  static int dflt = 0;
+  if (h) return h->num_cus;
+  if (!dflt) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      dflt = n;
+    else
+      dflt = 256;
+  }
+  return dflt;
+}
 
 void* ctx_workspace(vit_handle h, size_t* bytes) {
   if (!h) {
@@ -60,6 +75,7 @@ int vit_create(vit_handle* out, int device) {
   c->ws = nullptr;
   c->ws_bytes = 0;
   c->step_state = nullptr;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   *out = c;
   return VIT_OK;
 }

@@ -563,7 +563,7 @@ __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, i
     const int r = (j << 3) + (lane >> 3);
     const int c = p ^ swz<64>(r & 63);
     const int grow = min(row0 + r, T - 1);
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(g + (long)grow * ld + c * 8), (LDS_AS void*)(img + j * 1024), 16, 0, 0);
+    lds_dma16(g + (long)grow * ld + c * 8, img + j * 1024);
   }
 }
 
@@ -1655,13 +1655,463 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
   }
 }
 
+// ======================================================================================= pipelined fused backward (r03)
+// The persistent kernel above still ran its pieces one after the other: per (head, half) a phase A, a barrier, global loads
+// for the next head (K / V rows into registers, the O / O_lo / dO chunks and lse of the delta pre-pass), a phase B far too
+// short to cover them, another barrier -- 140 of its 364 us were that exposed chain (one workgroup per CU: nothing else
+// runs meanwhile), on top of 134 us of phase A that is VALU-bound.  This form removes every global -> register load and
+// every phase boundary from the critical path: the unit of work is a PAIR of query tiles (32 rows), one barrier per pair,
+// and in each barrier interval every stage of the backward runs for a DIFFERENT pair, on different waves:
+//
+//   iteration g:  top      B(g-1)   waves 6, 7: dQ of the two query tiles of pair g-1 = dS(g-1) K over all keys (dS image
+//                                   [key][32 q] written by A(g-1), K^T by transposing reads of the head's K image); stores
+//                          E        every wave, when pair g-1 ended its head: dK / dV of its key tiles + bias-gradient sums
+//                 issue    L(g+2)   LDS-DMA of pair g+2's rows into ring slot (g+2) % 3: Q (waves 0-3, 8 rows each) and
+//                                   dO, O, O_lo, lse (waves 4-7, 8 rows each); KV(h+1): the next head's K and V images,
+//                                   a few pieces per wave per iteration
+//                 A(g)              every wave, owner = key (tiles w and w + 8): S = Q K^T, dP = dO V^T, P, dS; dV += P^T dO,
+//                                   dK += dS^T Q in registers; dS (bf16) -> dS image g % 2.  K / V fragments are read from the
+//                                   LDS images when a head starts.  This is the VALU-bound stage; all else hides under it.
+//                 wait              s_waitcnt vmcnt(n): n = what THIS iteration issued, so L(g+1) (one iteration old) is in
+//                 D(g+1)   waves 4-7: delta = rowsum(dO (O + O_lo)), lse * log2 e, dropout row keys of the 8 rows whose
+//                                   data the wave loaded ITSELF (its own vmcnt wait orders them: no barrier needed)
+//                 barrier           publishes dS(g), statistics(g+1), the landed rows of pair g+1
+//
+// Nothing younger than an iteration's DMA is a store (stores sit at the top of the next iteration), so the counted wait
+// never drains a store or a prefetch.  13 key tiles at T = 197: waves 0-4 own two, waves 5-7 one -- and waves 4-7 carry the
+// D / B stages, so the four SIMDs (waves w and w + 4) are loaded about evenly.  Rows past T: DMA sources are clamped to row
+// T - 1, their probabilities are zero through lse = +inf (queries) / +inf added on the key side.
+// LDS: ring 3 x 16 KiB + lse staging 3 KiB + 2 K images + V image + 2 dS images [R][32] + statistics = 156 KiB at R = 208.
+// dh = 64, 64 <= T <= 208.  Deterministic, no atomics (basemodule.py:250).
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is wave-uniform; a smaller count than asked for is always safe
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
+}
+// one LDS-DMA piece: 8 rows x 128 B (image rows row_img .. + 7 of a [rows][64] bf16 matrix whose image row 0 is global row
+// grow0) into 1 KiB of consecutive LDS; SWZ: the tile image's XOR swizzle, applied to the lane's GLOBAL chunk
+template <bool SWZ>
+__device__ __forceinline__ void dma_piece(char* dst, const short* g, long ld, int row_img, int grow0, int T, int lane) {
+  const int r = row_img + (lane >> 3), pc = lane & 7;
+  const int c = SWZ ? (pc ^ swz<64>(r & 63)) : pc;
+  const int grow = min(grow0 + r, T - 1);
+  lds_dma16(g + (long)grow * ld + c * 8, dst);
+}
+// dS image of one pair: [key][32 queries] bf16, 64 B per key row, 8-byte slots (4 queries of one key) XOR-swizzled so that the
+// phase-A store (16 consecutive keys at one slot, banks mod 32) and the transposing read (8 consecutive keys x 4 adjacent
+// slots, banks mod 64) are both conflict-free: rows k and k + 2 share a 128-byte bank row half, rows k and k + 4 a quarter
+// of the 256-byte bank row -> slot ^ bits (k2, k3, k1)
+__device__ __forceinline__ int ds2_swz(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
+__device__ __forceinline__ int ds2_off(int key, int slot) { return key * 64 + ((slot ^ ds2_swz(key)) << 3); }
+
+constexpr int PIPE_SLOT = 16384, PIPE_NS = 3;
+#ifndef VIT_PIPE_SKIP  // timing variants only (python -m vit_amd.build --defs -DVIT_PIPE_SKIP=n --tag ..): 1 no B, 2 no A, 4 no DMA, 8 no D
+#define VIT_PIPE_SKIP 0
+#endif
+static size_t pipe_smem(int T) {
+  const size_t R = (T + 15) & ~15;
+  return PIPE_NS * PIPE_SLOT + PIPE_NS * 4 * 256 + 2 * R * 128 + R * 128 + 2 * R * 64 + 2 * 96 * 4;
+}
+
+#ifdef VIT_PIPE_STAMP  // diagnostic build only (tools/pipe_stamps.py): where an iteration of workgroup 0 goes, per wave
+__device__ unsigned long long g_pipe_st[8 * 8];
+#define PIPE_ST(K)                                                                   \
+  {                                                                                  \
+    unsigned long long t_;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    st_[K] += t_ - tprev_;                                                           \
+    tprev_ = t_;                                                                     \
+  }
+#else
+#define PIPE_ST(K)
+#endif
+
+// Two adjacent 16-column tiles of one 16-row block, packed to bf16 (a lane holds 4 consecutive columns of each: 8 bytes + 8
+// bytes), into ONE 16-byte store per lane: v_permlane16_swap trades the odd lane groups' first-tile data for the even
+// groups' second-tile data, so an even group ends with 8 consecutive columns of the first tile, an odd group with 8 of the
+// second.  Row-per-lane stores are issue-bound (each instruction touches 16 rows): half the instructions, half the time.
+// Returns this lane's first column within the 32-column pair.
+__device__ __forceinline__ int widen_pair(u32x2& a, u32x2& b, int lg) {
+  auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  a[0] = r0[0]; b[0] = r0[1];
+  a[1] = r1[0]; b[1] = r1[1];
+  return (lg & 1) ? 16 + 4 * (lg - 1) : 4 * lg;
+}
+
+struct PipeHead { int bh, b, hh; };
+
+__global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DH = 64, TILE = RT * DH * 2, RQ = 2, ND = DH / 16;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T, BH = p.B * p.H;
+  const long ld = 3L * p.H * DH, ldc = (long)p.H * DH, HD = (long)p.H * DH;
+  const int R = (T + 15) & ~15, nq = R >> 4, np = (nq + 1) >> 1, nks = (T + 31) >> 5;
+  char* ring = smem;
+  char* lse_raw = ring + PIPE_NS * PIPE_SLOT;  // [slot][row group][64 words]: raw lse, word l = lse of row (l >> 3) of the group
+  char* Kimg0 = lse_raw + PIPE_NS * 4 * 256;   // two K images (heads alternate)
+  char* Vimg = Kimg0 + 2 * R * 128;
+  char* dSb = Vimg + R * 128;                  // two dS images
+  float* stats = (float*)(dSb + 2 * R * 64);   // two sets of [lse 32 | delta 32 | dropout row key 32]
+  if ((int)blockIdx.x >= BH) return;
+  const int nheads = (BH - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int G = nheads * np;  // pairs this workgroup walks
+  const float c = p.scale * LOG2E;
+  const bool has_lo = p.ctx_lo != nullptr;
+  // roles: waves 0-3 load dO / O / O_lo / lse of 8 rows each and derive their statistics (D); waves 4-7 load Q and run the
+  // dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
+  const bool is_d = wave < 4, is_b = wave >= 4;
+  const int grp = wave & 3;
+  const int kt0 = wave, kt1 = wave + 8;  // this wave's key tiles
+  const bool own0 = kt0 * 16 < R, own1 = kt1 * 16 < R;
+  const float kinf[RQ] = {(kt0 * 16 + l15 < T) ? 0.f : INFINITY, (kt1 * 16 + l15 < T) ? 0.f : INFINITY};
+  // lane constants of the DMA pieces: a piece is 8 rows x 128 B; lane -> (row rl8 of the piece, 16-byte chunk); the image
+  // swizzle of rows 8 j + rl8 depends on rl8 only
+  const int rl8 = lane >> 3;
+  const int csw8 = ((lane & 7) ^ (rl8 & 6)) * 8, clin8 = (lane & 7) * 8;
+
+  auto head_of = [&](int hidx) -> PipeHead {  // the integer division happens here, once per head and pipeline position
+    PipeHead h;
+    h.bh = (int)blockIdx.x + hidx * (int)gridDim.x;
+    h.b = h.bh / p.H;
+    h.hh = h.bh - h.b * p.H;
+    return h;
+  };
+  auto qoff_of = [&](const PipeHead& h) -> long { return (long)h.b * T * ld + (long)h.hh * DH; };
+  auto coff_of = [&](const PipeHead& h) -> long { return (long)h.b * T * ldc + (long)h.hh * DH; };
+
+  // ---- L: the rows of pair pp of head h into ring slot s; returns the number of pieces this wave issued
+  auto issue_L = [&](const PipeHead& h, int pp, int s) -> int {
+    char* slot = ring + s * PIPE_SLOT;
+    const int row = min(pp * 32 + grp * 8 + rl8, T - 1);
+    if (is_b) {
+      lds_dma16(p.qkv + qoff_of(h) + (long)row * ld + csw8, slot + grp * 1024);
+      return 1;
+    }
+    const long ro = coff_of(h) + (long)row * ldc;
+    lds_dma16(p.dctx + ro + csw8, slot + 4096 + grp * 1024);
+    lds_dma16(p.ctx + ro + clin8, slot + 8192 + grp * 1024);
+    if (has_lo) lds_dma16(p.ctx_lo + ro + clin8, slot + 12288 + grp * 1024);
+    lds_dma4(p.lse + (long)h.bh * T + row, lse_raw + (s * 4 + grp) * 256);
+    return has_lo ? 4 : 3;
+  };
+  // ---- KV: pieces [j0, j0 + n) of a head's K image (buffer kbuf) and V image; piece j < R/8: K rows 8j.., else V
+  auto issue_KV = [&](const PipeHead& h, int kbuf, int j0, int n) -> int {
+    const int nk = R >> 3;
+    const short* kb_ = p.qkv + qoff_of(h) + HD;
+    char* Kd = Kimg0 + kbuf * (R * 128);
+    int cnt = 0;
+    for (int j = j0; j < j0 + n && j < 2 * nk; ++j) {
+      const bool isk = j < nk;
+      const int jj = isk ? j : j - nk;
+      const int row = min(jj * 8 + rl8, T - 1);
+      lds_dma16((isk ? kb_ : kb_ + HD) + (long)row * ld + csw8, (isk ? Kd : Vimg) + jj * 1024);
+      ++cnt;
+    }
+    return cnt;
+  };
+  const int kv_total = 2 * (R >> 3);
+  const int kvp = (kv_total + 8 * (np - 1) - 1) / (8 * (np - 1));  // pieces per wave per iteration, iterations pp = 1 .. np - 1
+
+  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
+  f32x4 dkt[RQ][ND], dvt[RQ][ND], csq[2];
+  csq[0] = csq[1] = zero4();
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
+  }
+  // B-stage lane constants: the transposing reads of the dS image (keys kb + 4 lg + tq (+ 16), this wave's query tile) and of
+  // the K image (same keys, the wave's two 16-column tiles); kb is a multiple of 32, which leaves both swizzles alone
+  const int tq = l15 >> 2, tp = l15 & 3;
+  const int bq = (wave >> 1) & 1, bd = wave & 1;  // query tile of the pair, dt pair (waves 4-7)
+  const int ds_lane = ds2_off(4 * lg + tq, bq * 4 + tp);
+  int k_lane[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int col = (bd * 2 + i) * 16 + 4 * tp;
+    k_lane[i] = (4 * lg + tq) * 128 + ((((col >> 3)) ^ ((4 * lg + tq) & 6)) << 4) + ((col >> 2) & 1) * 8;
+  }
+
+  // (head ordinal, pair) of g - 1, g, g + 1, g + 2; g runs from -2
+  int hm = 0, pm = -3, h0 = 0, p0 = -2, h1 = 0, p1 = -1, h2 = 0, p2 = 0;
+  PipeHead Hm = head_of(0), H0 = Hm, H1 = Hm, H2 = Hm, Hn = Hm;
+#ifdef VIT_PIPE_STAMP
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
+#endif
+  for (int g = -2; g <= G; ++g) {
+    const bool vm = g - 1 >= 0 && g - 1 < G, v0 = g >= 0 && g < G, v1 = g + 1 >= 0 && g + 1 < G, v2 = g + 2 < G;
+    // ------------------------------------------------------------------ top: B(g-1), head-end epilogue (stores)
+    if (vm) {
+      const bool head_done = pm == np - 1;
+      if (is_b && !(VIT_PIPE_SKIP & 1)) {
+        const int qt = pm * 2 + bq;
+        if (qt < nq) {
+          f32x4 dq0 = zero4(), dq1 = zero4();
+          const char* dcol = dSb + ((g - 1) & 1) * (R * 64) + ds_lane;
+          const char* Kh = Kimg0 + (hm & 1) * (R * 128);
+          const char* ka = Kh + k_lane[0];
+          const char* kb2 = Kh + k_lane[1];
+#pragma unroll
+          for (int ks = 0; ks < 7; ++ks) {  // T <= 208: at most 7 key steps of 32; every address is base + immediate
+            if (ks < nks) {
+              const bool hi_ok = ks * 32 + 16 < R;
+              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + ks * 2048));
+              bf16x4 hi = {0, 0, 0, 0};
+              if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + ks * 2048 + 1024));
+              const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              const int ho = hi_ok ? 2048 : 0;  // an un-staged block: its dS is 0, any staged rows will do
+              const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + ks * 4096));
+              const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + ks * 4096 + ho));
+              const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + ks * 4096));
+              const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + ks * 4096 + ho));
+              dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, dsf,
+                                                            dq0, 0, 0, 0);
+              dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]}, dsf,
+                                                            dq1, 0, 0, 0);
+            }
+          }
+          const int q = qt * 16 + l15;
+          const f32x4 v0_ = dq0 * p.scale, v1_ = dq1 * p.scale;
+          u32x2 pa = {pack2bf(v0_[0], v0_[1]), pack2bf(v0_[2], v0_[3])};
+          u32x2 pb = {pack2bf(v1_[0], v1_[1]), pack2bf(v1_[2], v1_[3])};
+          if (q < T) {
+            csq[0] += bf_round4(pa);
+            csq[1] += bf_round4(pb);
+          }
+          const int col = widen_pair(pa, pb, lg);
+          if (q < T)
+            *(u32x4*)(p.dqkv + ((long)Hm.b * T + q) * ld + Hm.hh * DH + bd * 32 + col) = (u32x4){pa[0], pa[1], pb[0], pb[1]};
+        }
+      }
+      if (head_done) {  // dK, dV of this wave's key tiles of head hm; per-wave column sums of everything this wave stored
+        f32x4 csk[ND], csv[ND];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) csk[dt] = csv[dt] = zero4();
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          const int key = (rq ? kt1 : kt0) * 16 + l15;
+          const bool okk = key < T;
+          short* ok = p.dqkv + ((long)Hm.b * T + key) * ld + HD + Hm.hh * DH;
+#pragma unroll
+          for (int dp = 0; dp < 2; ++dp) {
+            u32x2 pk[2], pv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const f32x4 a = dkt[rq][dp * 2 + i] * p.scale, v = dvt[rq][dp * 2 + i];
+              pk[i] = (u32x2){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+              pv[i] = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+              if (okk) {
+                csk[dp * 2 + i] += bf_round4(pk[i]);
+                csv[dp * 2 + i] += bf_round4(pv[i]);
+              }
+            }
+            const int col = widen_pair(pk[0], pk[1], lg);
+            widen_pair(pv[0], pv[1], lg);
+            if (okk) {
+              *(u32x4*)(ok + dp * 32 + col) = (u32x4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+              *(u32x4*)(ok + HD + dp * 32 + col) = (u32x4){pv[0][0], pv[0][1], pv[1][0], pv[1][1]};
+            }
+          }
+        }
+        if (p.csum_part) {  // one partial row per (batch, wave): [q third | k third | v third], this head's 64 columns of each
+          float* csum = p.csum_part + ((long)Hm.b * 8 + wave) * ld + Hm.hh * DH;
+#pragma unroll
+          for (int dt = 0; dt < ND; ++dt) {
+            f32x4 tq_ = zero4();  // a B wave summed dQ over its two 16-column tiles only
+            if (is_b && (dt >> 1) == bd) tq_ = rows16_sum(csq[dt & 1]);
+            const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
+            const int d = dt * 16 + lg * 4;
+            if (l15 == 0) {
+              *(f32x4*)(csum + d) = tq_;
+              *(f32x4*)(csum + HD + d) = tk;
+              *(f32x4*)(csum + 2 * HD + d) = tv;
+            }
+          }
+        }
+        csq[0] = csq[1] = zero4();
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
+        }
+      }
+    }
+    PIPE_ST(0)  // top: B(g-1) + head-end epilogue
+    // ------------------------------------------------------------------ issue: next head's K / V images, pair g + 2
+    int nissued = 0;
+    if (g == -2) {  // prologue: the first head's images, spread over the waves
+      const int per = (kv_total + 7) >> 3;
+      nissued += issue_KV(H2, 0, wave * per, per);
+    } else if (v0 && p0 >= 1 && h0 + 1 < nheads) {
+      if (p0 == 1) Hn = head_of(h0 + 1);
+      nissued += issue_KV(Hn, (h0 + 1) & 1, ((p0 - 1) * 8 + wave) * kvp, kvp);
+    }
+    if (v2 && !(VIT_PIPE_SKIP & 4)) nissued += issue_L(H2, p2, (g + 2) % PIPE_NS);
+    PIPE_ST(1)  // DMA issue
+    // ------------------------------------------------------------------ A(g)
+    if (v0) {
+      if (p0 == 0) {  // a head starts: this wave's K / V rows out of the images (landed and published an iteration ago or more)
+        const char* Kh = Kimg0 + (h0 & 1) * (R * 128);
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          const int k0 = (rq ? kt1 : kt0) * 16;
+          const bool ex = rq ? own1 : own0;
+#pragma unroll
+          for (int s = 0; s < DH / 32; ++s) {
+            kf[rq][s] = ex ? frag_rows<DH>(Kh + (k0 >> 6) * TILE, k0 & 63, s, l15, lg) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            vf[rq][s] = ex ? frag_rows<DH>(Vimg + (k0 >> 6) * TILE, k0 & 63, s, l15, lg) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          }
+        }
+      }
+      if (own0 && !(VIT_PIPE_SKIP & 2)) {
+        const char* Qt = ring + (g % PIPE_NS) * PIPE_SLOT;
+        const char* Ot = Qt + 4096;
+        const float* lse_s = stats + (g & 1) * 96;
+        const float* del_s = lse_s + 32;
+        const unsigned* rk_s = (const unsigned*)(del_s + 32);
+        char* dSw = dSb + (g & 1) * (R * 64);
+        u32x2 pdh[RQ][2], dsh[RQ][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
+          if (p0 * 32 + jj * 16 < R) {
+            f32x4 s_[RQ], dp[RQ];
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
+#pragma unroll
+            for (int s = 0; s < DH / 32; ++s) {
+              const bf16x8 qfr = frag_rows<DH>(Qt, jj * 16, s, l15, lg);
+              const bf16x8 ofr = frag_rows<DH>(Ot, jj * 16, s, l15, lg);
+#pragma unroll
+              for (int rq = 0; rq < RQ; ++rq) {
+                s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
+                dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
+              }
+            }
+            const f32x4 l4 = *(const f32x4*)(lse_s + jj * 16 + lg * 4);
+            const f32x4 d4 = *(const f32x4*)(del_s + jj * 16 + lg * 4);
+            const u32x4 rk4 = *(const u32x4*)(rk_s + jj * 16 + lg * 4);
+#pragma unroll
+            for (int rq = 0; rq < RQ; ++rq) {
+              if (rq == 1 && !own1) continue;
+              const unsigned key = (rq ? kt1 : kt0) * 16 + l15;
+              float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
+              if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
+                const float pr = fast_exp2(s_[rq][r] * c - (l4[r] + kinf[rq]));
+                pdv[r] = pr * mk[r];
+                dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
+              }
+              pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
+              dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
+              *(u32x2*)(dSw + ds2_off((int)key, jj * 4 + lg)) = dsh[rq][jj];
+            }
+          }
+        }
+        bf16x8 pf[RQ], df[RQ];
+#pragma unroll
+        for (int rq = 0; rq < RQ; ++rq) {
+          pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
+          df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
+        }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          // rows 16..31 of the slot always hold rows (clamped duplicates past T; their P and dS are 0)
+          const bf16x8 otf = frag_cols<DH>(Ot, 0, 16, dt * 16, l15, lg);
+          const bf16x8 qtf = frag_cols<DH>(Qt, 0, 16, dt * 16, l15, lg);
+#pragma unroll
+          for (int rq = 0; rq < RQ; ++rq) {
+            if (rq == 1 && !own1) continue;
+            dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
+            dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    PIPE_ST(2)  // A(g)
+    // ------------------------------------------------------------------ my pieces of pair g + 1 (one iteration old) are in
+    wait_vmcnt_dyn(nissued);
+    PIPE_ST(3)  // counted wait
+    // ------------------------------------------------------------------ D(g+1): statistics of the 8 rows this wave loaded
+    if (v1 && is_d && !(VIT_PIPE_SKIP & 8)) {
+      const int s1 = (g + 1) % PIPE_NS;
+      const char* slot = ring + s1 * PIPE_SLOT;
+      const int rl = grp * 8 + rl8, ch = lane & 7;
+      const bf16x8 d8 = *(const bf16x8*)(slot + 4096 + tile_off<DH>(rl, ch));
+      const bf16x8 o8 = *(const bf16x8*)(slot + 8192 + rl * 128 + ch * 16);
+      bf16x8 l8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (has_lo) l8 = *(const bf16x8*)(slot + 12288 + rl * 128 + ch * 16);
+      const float lraw = *(const float*)(lse_raw + (s1 * 4 + grp) * 256 + lane * 4);
+      float d_ = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(d8[e]);
+      d_ = sum_lanes_cpr<8>(d_);
+      const int grow = p1 * 32 + rl;
+      if (ch == 0) {
+        float* st = stats + ((g + 1) & 1) * 96;
+        st[rl] = grow < T ? lraw * LOG2E : INFINITY;
+        st[32 + rl] = grow < T ? d_ : 0.f;
+        ((unsigned*)st)[64 + rl] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)H1.bh * T + min(grow, T - 1)) : 0u;
+        if (grow < T) p.delta[(long)H1.bh * T + grow] = d_;
+      }
+    }
+    PIPE_ST(4)  // D(g+1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PIPE_ST(5)  // barrier
+    hm = h0; pm = p0; h0 = h1; p0 = p1; h1 = h2; p1 = p2;
+    Hm = H0; H0 = H1; H1 = H2;
+    if (++p2 == np) {
+      p2 = 0;
+      ++h2;
+      if (h2 < nheads) H2 = head_of(h2);
+    }
+  }
+#ifdef VIT_PIPE_STAMP
+  if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g_pipe_st[wave * 8 + k] = st_[k];
+    g_pipe_st[wave * 8 + 7] = (unsigned long long)(G + 3);
+  }
+#endif
+}
+#ifdef VIT_PIPE_STAMP
+}  // namespace vit
+extern "C" int vit_debug_pipe_stamps(unsigned long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(vit::g_pipe_st), 64 * sizeof(unsigned long long));
+}
+namespace vit {
+#endif
+
+static bool pipe_fits(int T, int dh) { return dh == 64 && T >= 64 && T <= 208 && pipe_smem(T) <= 160 * 1024; }
+
 static bool persist_fits(int T, int dh) {
   const size_t rows = (T + 15) & ~15;
   return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24) <= 160 * 1024;
 }
 
 int g_attn_debug = 0;
-int g_attn_bwd_fused = 3;  // vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent pipelined form where it fits (dh 64, T <= 224), else 1
+// vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent form where it fits
+// (dh 64, T <= 224), 4 (default) = the pair-pipelined form where it fits (dh 64, 64 <= T <= 208), else 3, else 1
+int g_attn_bwd_fused = 4;
 
 static bool fused_fits(int T, int dh) {
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
@@ -1972,8 +2422,9 @@ int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const v
     float* part = (float*)ctx_workspace(h, &wsb);
     const bool fused = g_attn_bwd_fused && fused_fits(T, dh);  // partial rows per batch: one per wave (8 / 16 waves), or in
     // the persistent form two per wave (one per half of the queries)
-    const bool persist = g_attn_bwd_fused == 3 && persist_fits(T, dh);
-    const int prow = fused ? B * (persist || g_attn_bwd_fused == 2 ? 16 : 8) : B * nsplit * wpw;
+    const bool pipe = g_attn_bwd_fused >= 4 && pipe_fits(T, dh);
+    const bool persist = !pipe && g_attn_bwd_fused >= 3 && persist_fits(T, dh);
+    const int prow = fused ? B * (pipe ? 8 : (persist || g_attn_bwd_fused == 2 ? 16 : 8)) : B * nsplit * wpw;
     if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
       // the resident kernels leave one partial row per wave: column sums of what they stored
       int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed,
@@ -2016,18 +2467,28 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
     const size_t rows = (T + 15) & ~15;
     const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 12);
-    if (g_attn_bwd_fused == 3 && persist_fits(T, dh)) {
+    if (g_attn_bwd_fused >= 4 && pipe_fits(T, dh)) {
+      static bool attr = false;
+      if (!attr) {
+        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+      }
+      hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(std::min(B * H, ctx_num_cus(h))), dim3(512), pipe_smem(T), st, a);
+      VIT_LAUNCH_CHECK();
+      return VIT_OK;
+    }
+    if (g_attn_bwd_fused >= 3 && persist_fits(T, dh)) {
       static bool attr = false;
       if (!attr) {
         VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
       }
       const size_t sm = 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24);
-      hipLaunchKernelGGL(attn_bwd_persist_kernel, dim3(std::min(B * H, 256)), dim3(512), sm, st, a);
+      hipLaunchKernelGGL(attn_bwd_persist_kernel, dim3(std::min(B * H, ctx_num_cus(h))), dim3(512), sm, st, a);
       VIT_LAUNCH_CHECK();
       return VIT_OK;
     }
-    const int nw = g_attn_bwd_fused == 2 ? 16 : 8;
+    const int nw = g_attn_bwd_fused == 2 ? 16 : 8;  // 3 / 4 that did not fit their forms: the 8-wave fused kernel
 #define LAUNCH_FUSED(DH_, NW_)                                                                                           \
   do {                                                                                                                   \
     static bool attr = false;                                                                                            \

@@ -175,9 +175,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 constexpr unsigned OOB = 0x80000000u;  // any voffset >= num_records reads as zero
 
+// ---- LDS-DMA by inline asm: global_load_lds_dwordx4 / _dword (16 / 4 bytes per lane from a per-lane global address to
+// LDS[M0 + lane * size], no VGPR destination).  NOT __builtin_amdgcn_global_load_lds: with the builtin the compiler knows an
+// LDS write is pending and, unable to prove that a transposing read does not alias it, writes `s_waitcnt vmcnt(0)` in front
+// of the first ds_read_b64_tr_b16 that follows -- once per K-tile phase in every GEMM with a transposed operand (dX, dW), and
+// in the attention kernels: the whole ring was drained although the hand-counted waits left 64 KiB in flight (r03 finding:
+// ISA of gemm3_kernel<*,1,*,*>; the plain ds_read_b128 forms were never affected).  The asm form is invisible to that pass;
+// these loads still count in vmcnt, in order, and every wait for them is a hand-counted s_waitcnt.  M0 is reserved by the
+// compiler and not otherwise used by these kernels; it is written in the statement that reads it (s_nop: M0 write -> use).
+#ifdef VIT_DMA_BUILTIN  // A/B variant build only (python -m vit_amd.build --defs -DVIT_DMA_BUILTIN --tag dmab): the builtin form
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+#else
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst /* wave-uniform */) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst /* wave-uniform */) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(a) : "memory");
+}
+#endif
+
 // the handle's bound per-step state (api.hip): [key0, key1, lr, bc1, rsqrt_bc2, step] in device memory, or NULL
 struct StepState { unsigned key0, key1; float lr, bc1, rsqrt_bc2; unsigned step; };
 const StepState* ctx_step_state(vit_handle h);
+int ctx_num_cus(vit_handle h);  // compute units of the handle's device (api.hip)
 static inline DropCfg make_drop_h(vit_handle h, float p, uint64_t seed, uint64_t site) {
   DropCfg d = make_drop(p, seed, site);
   const StepState* s = h ? ctx_step_state(h) : nullptr;

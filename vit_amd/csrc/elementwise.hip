@@ -232,6 +232,18 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, short* __res
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nv << 2) + threadIdx.x] = f2bf(src[(nv << 2) + threadIdx.x]);
 }
 
+// dst (f32) = scale * src (bf16): the receive side of a bf16 gradient exchange (vit_amd/ddp.py)
+__global__ void cast_bf16_f32_kernel(const short* __restrict__ src, float* __restrict__ dst, long n, float scale) {
+  const long nv = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    const u32x2 pk = *(const u32x2*)(src + 4 * i);
+    f32x4 v = {__builtin_bit_cast(float, pk[0] << 16) * scale, __builtin_bit_cast(float, pk[0] & 0xFFFF0000u) * scale,
+               __builtin_bit_cast(float, pk[1] << 16) * scale, __builtin_bit_cast(float, pk[1] & 0xFFFF0000u) * scale};
+    *(f32x4*)(dst + 4 * i) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nv << 2) + threadIdx.x] = bf2f(src[(nv << 2) + threadIdx.x]) * scale;
+}
+
 // ------------------------------------------------------------------------------------------ head + loss
 // one wave per sample: logits[b, c] = <last_hidden[b, 0, :], W[c, :]> + bias[c]
 __global__ __launch_bounds__(64) void head_logits_kernel(const float* __restrict__ last, const float* __restrict__ W,
@@ -632,6 +644,16 @@ int vit_cast_f32_bf16(vit_handle h, const float* src, void* dst, int64_t n, vit_
   VIT_CHECK(src && dst && n > 0, VIT_ERR_ARG, "vit_cast_f32_bf16: bad arguments");
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, src, (short*)dst,
                      (long)n);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int vit_cast_bf16_f32(vit_handle h, const void* src, float* dst, int64_t n, float scale, vit_stream stream) {
+  (void)h;
+  VIT_CHECK(src && dst && n > 0, VIT_ERR_ARG, "vit_cast_bf16_f32: bad arguments");
+  VIT_CHECK((((uintptr_t)src) & 7) == 0 && (((uintptr_t)dst) & 15) == 0, VIT_ERR_ARG, "vit_cast_bf16_f32: src must be 8-byte, dst 16-byte aligned");
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (const short*)src, dst,
+                     (long)n, scale);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
 }

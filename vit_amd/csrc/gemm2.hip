@@ -230,10 +230,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm2_kernel(Gemm2Args p) {
     char* st = smem + (it % NSTAGE) * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < GA; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(ab + (long)offA[i] * 2), (LDS_AS void*)(st + i * RND), 16, 0, 0);
+      lds_dma16(ab + (long)offA[i] * 2, st + i * RND);
 #pragma unroll
     for (int i = 0; i < GB; ++i)
-      __builtin_amdgcn_global_load_lds((GLB_AS void*)(bb + (long)offB[i] * 2), (LDS_AS void*)(st + A_BYTES + i * RND), 16, 0, 0);
+      lds_dma16(bb + (long)offB[i] * 2, st + A_BYTES + i * RND);
   };
 
   // ---- fragment read offsets
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
 #ifdef VIT_PP_DIAG  // diagnostic build only (tools/pp_diag.py): 16 = no operand DMA, 32 = no fragment reads, 64 = no MFMAs, 128 = no epilogue
     if (p.debug & 16) return;
 #endif
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (half_off + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
+    lds_dma16(base + (half_off + off[0]) * 2, dst);
+    lds_dma16(base + (half_off + off[1]) * 2, dst + 8192);
   };
 
   // ---- fragment reads
@@ -1035,8 +1035,8 @@ __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
   auto issue_half = [&](const char* base, long off_el, const int (&off)[2]) {
     char* dst = smem + dofs + wave * 1024;
     dofs = (dofs + HALF) & (NSLOT * HALF - 1);
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[0]) * 2), (LDS_AS void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((GLB_AS void*)(base + (off_el + off[1]) * 2), (LDS_AS void*)(dst + 8192), 16, 0, 0);
+    lds_dma16(base + (off_el + off[0]) * 2, dst);
+    lds_dma16(base + (off_el + off[1]) * 2, dst + 8192);
   };
 
   const int tq = l15 >> 2, tp = l15 & 3;

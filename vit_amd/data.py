@@ -19,7 +19,7 @@ from typing import Iterator, Optional, Sequence, Tuple
 
 import torch
 
-__all__ = ["SpecDataset", "SpecLoader"]
+__all__ = ["SpecDataset", "SpecLoader", "SpecDataModule"]
 
 
 class SpecDataset:
@@ -29,6 +29,12 @@ class SpecDataset:
         self.error = torch.as_tensor(error, dtype=torch.float32)
         if self.error.shape != self.flux.shape:
             raise ValueError("flux and error must have the same shape")
+        if self.error.dim() == 2 and self.error.shape[1] > 1 and bool(self.error.isnan().any()):  # base.py:210-215, 238-239
+            self.error = self.error.clone()
+            if bool(self.error[:, 0].isnan().any()):
+                self.error[:, 0] = self.error[:, 1]
+            if bool(self.error[:, -1].isnan().any()):
+                self.error[:, -1] = self.error[:, -2]
         params = torch.as_tensor(params)
         self.task, self.stage, self.label_norm, self.noise_level = task, stage, label_norm, float(noise_level)
         self.stats = dict(stats or {})
@@ -75,13 +81,16 @@ class SpecDataset:
         return self.flux[idx], self.error[idx], self.labels[idx]
 
     @classmethod
-    def from_npz(cls, path, param_keys: Sequence[str] = ("log_g",), **kw):
+    def from_npz(cls, path, param_keys: Sequence[str] = ("log_g",), num_samples: Optional[int] = None, **kw):
         import numpy as np
 
-        raw = np.load(path)
-        cols = [torch.from_numpy(raw[k]).float() for k in param_keys]
+        raw = np.load(path)  # allow_pickle stays False: arrays only
+        for k in ("flux", "error", *param_keys):
+            if k not in raw.files:
+                raise KeyError(f"Requested array '{k}' not found in {path}: {list(raw.files)}")
+        cols = [torch.from_numpy(np.asarray(raw[k][:num_samples])).float() for k in param_keys]
         params = cols[0] if len(cols) == 1 else torch.stack(cols, dim=1)
-        return cls(raw["flux"], raw["error"], params, **kw)
+        return cls(raw["flux"][:num_samples], raw["error"][:num_samples], params, **kw)
 
     @classmethod
     def from_hdf5(cls, path, num_samples: Optional[int] = None, param_keys: Sequence[str] = ("log_g",), **kw):
@@ -121,3 +130,92 @@ class SpecLoader:
             if self.drop_last and len(j) < self.bs:
                 break
             yield self.ds[j]
+
+
+class SpecDataModule:
+    """What `ViTDataModule.from_config(config)` + `BaseDataModule.setup / *_dataloader` give the reference's trainer
+    (src/vit.py:29-50, src/basemodule.py:38-127), over this module's `SpecDataset` / `SpecLoader`:
+
+      data.file_path  -> training split (first `data.num_samples` rows)            shuffled unless `train.debug`
+      data.val_path   -> validation split (first `data.num_test_samples` rows)     batch = min(train.batch_size, len(val))
+      data.test_path  -> test split (first `data.num_test_samples` rows)
+      data.param ('log_g' | 'a,b' | [a, b]), data.label_norm, noise.noise_level as in the reference's dataset classes; the
+      label statistics of the TRAINING split are re-used on val / test (vit.py:42-50); val / test spectra carry their
+      fixed-seed noise (base.py:312-326).
+
+    Files: `.npz` with arrays `flux`, `error` and one array per parameter name (this image has no h5py), or the reference's
+    HDF5 layout (`dataset/arrays/{flux,error}/value` + a pandas parameter table: base.py:227-297) when h5py imports."""
+
+    def __init__(self, config: dict):
+        self.config = config
+        data, train = config.get("data", {}) or {}, config.get("train", {}) or {}
+        model = config.get("model", {}) or {}
+        task = (model.get("task_type") or model.get("task") or "cls").lower()
+        self.task = "cls" if task in ("classification", "cls", "class") else "reg"  # vit.py:20-26
+        self.paths = {"train": data.get("file_path") or data.get("train_path"), "val": data.get("val_path"),
+                      "test": data.get("test_path")}
+        self.num_samples = data.get("num_samples")
+        self.num_test_samples = data.get("num_test_samples")
+        prm = data.get("param")
+        if isinstance(prm, str):
+            prm = [x.strip() for x in prm.split(",") if x.strip()]
+        self.param_keys = list(prm) if prm else []
+        if self.task == "reg" and not self.param_keys:
+            raise ValueError("Regression requires 'data.param' to be set in the config (string, comma-separated string, or "
+                             "list).")  # spec_datasets.py:52-57
+        if self.task == "cls" and not self.param_keys:
+            self.param_keys = ["log_g"]  # spec_datasets.py:24
+        self.label_norm = data.get("label_norm", "none")
+        self.noise_level = float((config.get("noise", {}) or {}).get("noise_level", 0.0) or 0.0)
+        self.batch_size = int(train.get("batch_size", 64))
+        self.debug = bool(train.get("debug", False))
+        self.train = self.val = self.test = None
+
+    @classmethod
+    def from_config(cls, config: dict) -> "SpecDataModule":
+        return cls(config)
+
+    def available(self, stage: str = "train") -> bool:
+        import os
+
+        path = self.paths.get(stage)
+        return bool(path) and os.path.exists(path)
+
+    def _load(self, stage: str, stats):
+        import os
+
+        path = self.paths["train" if stage == "train" else stage]
+        if not path or not os.path.exists(path):
+            raise FileNotFoundError(f"[{stage}] Data file not found: {path}")  # base.py:224-225
+        n = self.num_samples if stage == "train" else self.num_test_samples
+        kw = dict(task=self.task, stage=stage, label_norm=self.label_norm, noise_level=self.noise_level, stats=stats)
+        print(f"[{stage}] loading data from {path}, num_samples={n}")
+        if path.endswith((".h5", ".hdf5", ".hdf")):
+            return SpecDataset.from_hdf5(path, num_samples=n, param_keys=self.param_keys, **kw)
+        return SpecDataset.from_npz(path, param_keys=self.param_keys, num_samples=n, **kw)
+
+    def setup(self, stage: str = "fit"):
+        if stage in ("fit", None):
+            self.train = self._load("train", None)
+            if self.paths["val"]:
+                self.val = self._load("val", self.train.stats)
+        elif stage == "test":
+            stats = self.train.stats if self.train is not None else None
+            if stats is None and self.label_norm in ("standard", "zscore", "minmax") and self.task == "reg":
+                # evaluation only: the statistics still come from the training split (the reference's test-only entry builds
+                # the training dataset first for the same reason: Experiment.__init__ -> data_module.setup('fit'))
+                stats = self._load("train", None).stats
+            self.test = self._load("test", stats)
+        return self
+
+    def train_dataloader(self) -> "SpecLoader":
+        return SpecLoader(self.train, self.batch_size, shuffle=not self.debug)
+
+    def val_dataloader(self):
+        if self.val is None or len(self.val) == 0:
+            print("[WARNING] Validation dataset is None or empty - validation will be skipped")  # basemodule.py:88-94
+            return None
+        return SpecLoader(self.val, min(max(self.batch_size, 1), len(self.val)))
+
+    def test_dataloader(self) -> "SpecLoader":
+        return SpecLoader(self.test, self.batch_size)

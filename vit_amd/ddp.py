@@ -82,48 +82,87 @@ def shard_indices(n: int, rank: int, world: int, epoch: int, shuffle: bool, seed
 class GradAllReducer:
     """Mean all-reduce of the slices [lo, hi) of one flat gradient buffer, launched as they become ready."""
 
-    def __init__(self, grads_getter, buckets: List[Tuple[int, int]], group=None, max_bucket_elems: int = 64 << 20):
+    def __init__(self, grads_getter, buckets: List[Tuple[int, int]], group=None, max_bucket_elems: int = 64 << 20,
+                 grad_dtype: str = "fp32"):
+        """`grad_dtype='bf16'` (`train.ddp_grad_dtype`, SURVEY.md section 5: 172 MB instead of 343 MB per step on the links):
+        each bucket is cast into a bf16 send buffer, that buffer is all-reduced, and the result is cast back into the fp32
+        gradient buffer at the join.  The SUM then runs in bf16 inside the collective library (RCCL has no fp32-accumulate
+        mode for bf16 payloads): every rank's gradient is rounded to 8 significant bits before it is added, so this is an
+        option with a measured parity cost (tests/test_ddp_cpu.py, tests/test_ddp_gpu.py), never the default -- the
+        reference's DDP exchanges fp32 gradients (src/hardware_utils.py:86-95)."""
         self._get = grads_getter
         self.buckets = buckets
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = exchange_active(group)
+        if max_bucket_elems % 8:
+            raise ValueError("max_bucket_elems must be a multiple of 8 (16-byte aligned bf16 pieces)")
         self.max_bucket_elems = max_bucket_elems
+        gd = str(grad_dtype or "fp32").lower()
+        if gd not in ("fp32", "f32", "float32", "32", "bf16", "bfloat16"):
+            raise ValueError(f"unknown train.ddp_grad_dtype '{grad_dtype}' (use 'fp32' or 'bf16')")
+        self.grad_dtype = "bf16" if gd in ("bf16", "bfloat16") else "fp32"
+        self._send: Optional[torch.Tensor] = None
         self._pending = []
         self._seen = 0
         self.bytes_reduced = 0
         self.mode = "allreduce"
         # what one step puts on the wire (for bench.py's `comm` object)
         self.calls_per_step = sum(-(-(hi - lo) // max_bucket_elems) for lo, hi in buckets if hi > lo)
-        self.bytes_per_step = 4 * sum(hi - lo for lo, hi in buckets if hi > lo)
+        self.bytes_per_step = (2 if self.grad_dtype == "bf16" else 4) * sum(hi - lo for lo, hi in buckets if hi > lo)
+
+    @staticmethod
+    def _to_bf16(src: torch.Tensor, dst: torch.Tensor):
+        if src.is_cuda:
+            from . import functional as vf
+
+            vf.cast_f32_bf16(src, dst)
+        else:
+            dst.copy_(src)
+
+    @staticmethod
+    def _from_bf16(src: torch.Tensor, dst: torch.Tensor, scale: float):
+        if src.is_cuda:
+            from . import functional as vf
+
+            vf.cast_bf16_f32(src, dst, scale)
+        else:
+            dst.copy_(src.float() * scale)
 
     def bucket_ready(self, lo: int, hi: int):
         """Engine callback (called on the host right after the kernels that complete grads[lo:hi] were enqueued)."""
         if not self.active or hi <= lo:
             return
         g = self._get()
+        backend = dist.get_backend(self.group)
+        if self.grad_dtype == "bf16" and (self._send is None or self._send.numel() != g.numel() or self._send.device != g.device):
+            self._send = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
         # an all-reduce bigger than max_bucket_elems is split so that the first pieces are on the wire early
         for a in range(lo, hi, self.max_bucket_elems):
             b = min(hi, a + self.max_bucket_elems)
-            t = g[a:b]
-            backend = dist.get_backend(self.group)
+            t, back = g[a:b], None
+            if self.grad_dtype == "bf16":
+                back, t = t, self._send[a:b]
+                self._to_bf16(back, t)
             if backend == "nccl":
                 w = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-                self._pending.append((w, None))
+                self._pending.append((w, t, back, 1.0))
             else:
                 if t.is_cuda:  # gloo reads the tensor on the host side: the producing kernels must have finished
                     torch.cuda.current_stream(t.device).synchronize()
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._pending.append((w, t))
+                self._pending.append((w, t, back, 1.0 / self.world))
             self.bytes_reduced += t.numel() * t.element_size()
         self._seen += 1
 
     def finish(self):
         """Join every outstanding all-reduce (the compute stream waits on RCCL's stream; no host sync with nccl)."""
-        for w, t in self._pending:
+        for w, t, back, scale in self._pending:
             w.wait()
-            if t is not None:
-                t.div_(self.world)
+            if back is not None:  # bf16 exchange: back into the fp32 gradient buffer (and the mean, where the library summed)
+                self._from_bf16(t, back, scale)
+            elif scale != 1.0:
+                t.mul_(scale)
         self._pending = []
         self._seen = 0
 
@@ -140,8 +179,11 @@ class ShardedGradReducer(GradAllReducer):
     The clipping norm = sum over the all-reduced buckets (identical everywhere) + all-reduce of the ranks' shard sums.
     gloo has no reduce-scatter: there the bucket is all-reduced and the rank then simply uses its shard (same values)."""
 
-    def __init__(self, grads_getter, buckets, group=None, max_bucket_elems: int = 64 << 20):
-        super().__init__(grads_getter, buckets, group, max_bucket_elems)
+    def __init__(self, grads_getter, buckets, group=None, max_bucket_elems: int = 64 << 20, grad_dtype: str = "fp32"):
+        super().__init__(grads_getter, buckets, group, max_bucket_elems, grad_dtype)
+        if self.grad_dtype != "fp32":
+            raise ValueError("train.ddp_grad_dtype='bf16' is offered with the all-reduce exchange only (the sharded schedule "
+                             "reduce-scatters in place in the fp32 gradient buffer)")
         self.mode = "zero1"
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.sharded = [(hi - lo) > 0 and (hi - lo) % (8 * self.world) == 0 for lo, hi in buckets]
@@ -163,7 +205,7 @@ class ShardedGradReducer(GradAllReducer):
         g = self._get()
         a, b = self.shard(lo, hi)
         w = dist.reduce_scatter_tensor(g[a:b], g[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        self._pending.append((w, None))
+        self._pending.append((w, g[a:b], None, 1.0))
         self.bytes_reduced += (hi - lo) * 4
 
     def all_gather_params(self, flat: torch.Tensor):
@@ -187,11 +229,11 @@ class ShardedGradReducer(GradAllReducer):
             w.wait()
 
 
-def make_reducer(kind: str, engine, group=None):
+def make_reducer(kind: str, engine, group=None, grad_dtype: str = "fp32", max_bucket_elems: int = 64 << 20):
     """'allreduce' (default) or 'zero1' over the engine's flat gradient buffer and its backward-ordered buckets."""
     kind = (kind or "allreduce").lower()
     if kind in ("allreduce", "all_reduce", "ar"):
-        return GradAllReducer(lambda: engine.grads, engine.layout.buckets(), group)
+        return GradAllReducer(lambda: engine.grads, engine.layout.buckets(), group, max_bucket_elems, grad_dtype)
     if kind in ("zero1", "reduce_scatter", "rs"):
-        return ShardedGradReducer(lambda: engine.grads, engine.layout.buckets(), group)
+        return ShardedGradReducer(lambda: engine.grads, engine.layout.buckets(), group, max_bucket_elems, grad_dtype)
     raise ValueError(f"unknown train.ddp_exchange '{kind}' (use 'allreduce' or 'zero1')")

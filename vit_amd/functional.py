@@ -331,6 +331,15 @@ def cast_f32_bf16(src, out=None):
     return out
 
 
+def cast_bf16_f32(src, out, scale: float = 1.0):
+    """out (f32) = scale * src (bf16)."""
+    _chk(src, torch.bfloat16, "cast_bf16_f32 src")
+    _chk(out, torch.float32, "cast_bf16_f32 out")
+    h = _h(src)
+    check(h.lib.vit_cast_bf16_f32(h.h, src.data_ptr(), out.data_ptr(), src.numel(), float(scale), _stream(src)), "vit_cast_bf16_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ head + loss
 def head_loss_fwd(last_hidden, W, b, labels, loss_kind: int):
     _chk(last_hidden, torch.float32, "head_loss_fwd last_hidden")

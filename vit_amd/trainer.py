@@ -170,6 +170,9 @@ class Trainer:
         self.exchanging = ddp_mod.exchange_active()  # world > 1, or the single-rank RCCL rehearsal (VIT_DIST_SINGLE)
         self.backend = torch.distributed.get_backend() if self.exchanging else None
         self.exchange = str(config.get("ddp_exchange", os.environ.get("VIT_DDP_EXCHANGE", "allreduce")))
+        # 'fp32' (the reference's DDP) | 'bf16' (half the bytes on the links, the sum rounded in bf16: an option, see ddp.py)
+        self.grad_dtype = str(config.get("ddp_grad_dtype", os.environ.get("VIT_DDP_GRAD_DTYPE", "fp32")))
+        self.max_bucket_elems = int(config.get("ddp_max_bucket_elems", os.environ.get("VIT_DDP_MAX_BUCKET_ELEMS", 64 << 20)))
         # train.hip_graph: replay the optimisation step as one captured hipGraph (vit_amd/graph.py; single GPU only)
         self.use_graph = bool(config.get("hip_graph", False))
         self._graphed = None
@@ -231,7 +234,8 @@ class Trainer:
             eng._ensure_device_state()
             ddp_mod.broadcast_parameters(eng.flat)
             eng._shadow_version = -1
-            self.reducer = ddp_mod.make_reducer(self.exchange, eng)
+            self.reducer = ddp_mod.make_reducer(self.exchange, eng, grad_dtype=self.grad_dtype,
+                                                max_bucket_elems=self.max_bucket_elems)
             eng.grad_ready_cb = self.reducer.bucket_ready
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.set_grad_clip(self.gradient_clip_val)
