@@ -25,9 +25,9 @@ lib = _cabi.load()
 buf = (ctypes.c_ulonglong * 64)()
 lib.vit_debug_pipe_stamps.argtypes = [ctypes.c_void_p]
 assert lib.vit_debug_pipe_stamps(buf) == 0
-names = ["top(B+E)", "issue", "A", "wait", "D", "barrier"]
+names = ["E", "issue", "A", "wait", "D", "barrier", "B"]
 print("cycles per iteration (workgroup 0):  " + "  ".join(f"{n:>9s}" for n in names) + "      total")
 for w in range(8):
     it = buf[w * 8 + 7]
-    v = [buf[w * 8 + k] / it for k in range(6)]
+    v = [buf[w * 8 + k] / it for k in range(7)]
     print(f"wave {w}:                              " + "  ".join(f"{x:9.0f}" for x in v) + f"  {sum(v):9.0f}")

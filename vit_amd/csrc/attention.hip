@@ -1693,7 +1693,11 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is wave-uniform; a
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
 }
 // one LDS-DMA piece: 8 rows x 128 B (image rows row_img .. + 7 of a [rows][64] bf16 matrix whose image row 0 is global row
@@ -1775,13 +1779,17 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   // dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
   const bool is_d = wave < 4, is_b = wave >= 4;
   const int grp = wave & 3;
-  const int kt0 = wave, kt1 = wave + 8;  // this wave's key tiles
+  // this wave's key tiles: tile w, and of the tiles past 8 first the four for waves 0-3, then wave 7, 6, 5, 4 -- waves 4-7 carry
+  // the dQ stage, the heavier extra (stamps), and the second query tile's pair (6, 7) is idle in a head's last iteration
+  const int kt0 = wave, kt1 = wave < 4 ? 8 + wave : 19 - wave;
   const bool own0 = kt0 * 16 < R, own1 = kt1 * 16 < R;
   const float kinf[RQ] = {(kt0 * 16 + l15 < T) ? 0.f : INFINITY, (kt1 * 16 + l15 < T) ? 0.f : INFINITY};
-  // lane constants of the DMA pieces: a piece is 8 rows x 128 B; lane -> (row rl8 of the piece, 16-byte chunk); the image
-  // swizzle of rows 8 j + rl8 depends on rl8 only
-  const int rl8 = lane >> 3;
-  const int csw8 = ((lane & 7) ^ (rl8 & 6)) * 8, clin8 = (lane & 7) * 8;
+  // Lane constants of the stages OUTSIDE the A stage are derived from an opaque copy of the lane id inside each iteration
+  // (`ln` below): hoisted out of the loop they stayed live across the A stage, whose registers then spilled to scratch --
+  // and a scratch reload is a vector-memory load the compiler waits for with vmcnt(0), draining the LDS-DMA just issued.
+  // A DMA piece is 8 rows x 128 B: lane -> (row rl8 of the piece, 16-byte chunk); the image swizzle of rows 8 j + rl8
+  // depends on rl8 only.
+  int rl8, csw8, clin8;
 
   auto head_of = [&](int hidx) -> PipeHead {  // the integer division happens here, once per head and pipeline position
     PipeHead h;
@@ -1795,18 +1803,18 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
 
   // ---- L: the rows of pair pp of head h into ring slot s; returns the number of pieces this wave issued
   auto issue_L = [&](const PipeHead& h, int pp, int s) -> int {
+    // waves 0-3 issue every piece of their 8 rows (Q too): the address set-up of an issue costs ~1 000 cycles per wave however
+    // few pieces follow (stamps), and waves 4-7 carry the dQ stage -- they issue nothing
     char* slot = ring + s * PIPE_SLOT;
     const int row = min(pp * 32 + grp * 8 + rl8, T - 1);
-    if (is_b) {
-      lds_dma16(p.qkv + qoff_of(h) + (long)row * ld + csw8, slot + grp * 1024);
-      return 1;
-    }
+    if (is_b) return 0;
+    lds_dma16(p.qkv + qoff_of(h) + (long)row * ld + csw8, slot + grp * 1024);
     const long ro = coff_of(h) + (long)row * ldc;
     lds_dma16(p.dctx + ro + csw8, slot + 4096 + grp * 1024);
     lds_dma16(p.ctx + ro + clin8, slot + 8192 + grp * 1024);
     if (has_lo) lds_dma16(p.ctx_lo + ro + clin8, slot + 12288 + grp * 1024);
     lds_dma4(p.lse + (long)h.bh * T + row, lse_raw + (s * 4 + grp) * 256);
-    return has_lo ? 4 : 3;
+    return has_lo ? 5 : 4;
   };
   // ---- KV: pieces [j0, j0 + n) of a head's K image (buffer kbuf) and V image; piece j < R/8: K rows 8j.., else V
   auto issue_KV = [&](const PipeHead& h, int kbuf, int j0, int n) -> int {
@@ -1824,7 +1832,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     return cnt;
   };
   const int kv_total = 2 * (R >> 3);
-  const int kvp = (kv_total + 8 * (np - 1) - 1) / (8 * (np - 1));  // pieces per wave per iteration, iterations pp = 1 .. np - 1
+  const int kvp = (kv_total + 4 * (np - 1) - 1) / (4 * (np - 1));  // pieces per issuing wave (0-3) per iteration pp = 1 .. np - 1
 
   bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
   f32x4 dkt[RQ][ND], dvt[RQ][ND], csq[2];
@@ -1834,27 +1842,26 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
   }
-  // B-stage lane constants: the transposing reads of the dS image (keys kb + 4 lg + tq (+ 16), this wave's query tile) and of
-  // the K image (same keys, the wave's two 16-column tiles); kb is a multiple of 32, which leaves both swizzles alone
-  const int tq = l15 >> 2, tp = l15 & 3;
-  const int bq = (wave >> 1) & 1, bd = wave & 1;  // query tile of the pair, dt pair (waves 4-7)
-  const int ds_lane = ds2_off(4 * lg + tq, bq * 4 + tp);
-  int k_lane[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int col = (bd * 2 + i) * 16 + 4 * tp;
-    k_lane[i] = (4 * lg + tq) * 128 + ((((col >> 3)) ^ ((4 * lg + tq) & 6)) << 4) + ((col >> 2) & 1) * 8;
-  }
+  const int bq = (wave >> 1) & 1, bd = wave & 1;  // B stage: query tile of the pair, dt pair (waves 4-7)
 
   // (head ordinal, pair) of g - 1, g, g + 1, g + 2; g runs from -2
   int hm = 0, pm = -3, h0 = 0, p0 = -2, h1 = 0, p1 = -1, h2 = 0, p2 = 0;
   PipeHead Hm = head_of(0), H0 = Hm, H1 = Hm, H2 = Hm, Hn = Hm;
+#ifdef VIT_PIPE_PRIO  // experiment: the second-dispatched half (waves 4-7) loses issue arbitration to the older half
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef VIT_PIPE_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
 #endif
   for (int g = -2; g <= G; ++g) {
     const bool vm = g - 1 >= 0 && g - 1 < G, v0 = g >= 0 && g < G, v1 = g + 1 >= 0 && g + 1 < G, v2 = g + 2 < G;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: what derives from it is recomputed per iteration, not kept across the A stage
+    const int l15o = ln & 15, lgo = ln >> 4;
+    rl8 = ln >> 3;
+    csw8 = ((ln & 7) ^ (rl8 & 6)) * 8;
+    clin8 = (ln & 7) * 8;
     // ------------------------------------------------------------------ top: B(g-1), head-end epilogue (stores)
     if (vm) {
       const bool head_done = pm == np - 1;
@@ -1862,30 +1869,59 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
         const int qt = pm * 2 + bq;
         if (qt < nq) {
           f32x4 dq0 = zero4(), dq1 = zero4();
-          const char* dcol = dSb + ((g - 1) & 1) * (R * 64) + ds_lane;
+          // the transposing reads of the dS image (keys kb + 4 lg + tq (+ 16), this wave's query tile) and of the K image
+          // (same keys, the wave's two 16-column tiles); kb is a multiple of 32, which leaves both swizzles alone
+          const int tq = l15o >> 2, tp = l15o & 3, krow = 4 * lgo + tq;
+          int k_lane[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int col = (bd * 2 + i) * 16 + 4 * tp;
+            k_lane[i] = krow * 128 + ((((col >> 3)) ^ (krow & 6)) << 4) + ((col >> 2) & 1) * 8;
+          }
+          const char* dcol = dSb + ((g - 1) & 1) * (R * 64) + ds2_off(krow, bq * 4 + tp);
           const char* Kh = Kimg0 + (hm & 1) * (R * 128);
           const char* ka = Kh + k_lane[0];
           const char* kb2 = Kh + k_lane[1];
+          // T <= 208: at most 7 key steps of 32.  Branch-free (a step past the last reads step 0 again and its dS fragment is
+          // zeroed; a 16-key block that is not staged reads the block before it, zeroed likewise), so that the fragment reads
+          // of two steps are in flight while the MFMAs of the two steps before them run: as one basic block per step the
+          // stage was a chain of 7 LDS round trips (3 900 cycles per pair in the stamps, the critical path of the iteration).
+          struct BFrag { bf16x8 ds, a, b; };
+          auto bload = [&](int ks) -> BFrag {
+            const bool on = ks < nks, hi_ok = on && ks * 32 + 16 < R;
+            const int od = on ? ks * 2048 : 0, okk = on ? ks * 4096 : 0, oh = hi_ok ? 1 : 0;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + od));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + od + oh * 1024));
+            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + okk));
+            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + okk + oh * 2048));
+            const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + okk));
+            const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + okk + oh * 2048));
+            const bf16x4 z = {0, 0, 0, 0};
+            lo = on ? lo : z;
+            hi = hi_ok ? hi : z;
+            BFrag f;
+            f.ds = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            f.a = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            f.b = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            return f;
+          };
+          auto bmma = [&](const BFrag& f) {
+            dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a, f.ds, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b, f.ds, dq1, 0, 0, 0);
+          };
+          {  // two steps of fragments in flight (24 VGPRs): deeper prefetch spilled the A stage's registers to scratch
+            BFrag fa = bload(0), fb = bload(1);
 #pragma unroll
-          for (int ks = 0; ks < 7; ++ks) {  // T <= 208: at most 7 key steps of 32; every address is base + immediate
-            if (ks < nks) {
-              const bool hi_ok = ks * 32 + 16 < R;
-              const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + ks * 2048));
-              bf16x4 hi = {0, 0, 0, 0};
-              if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + ks * 2048 + 1024));
-              const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-              const int ho = hi_ok ? 2048 : 0;  // an un-staged block: its dS is 0, any staged rows will do
-              const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + ks * 4096));
-              const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(ka + ks * 4096 + ho));
-              const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + ks * 4096));
-              const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(kb2 + ks * 4096 + ho));
-              dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]}, dsf,
-                                                            dq0, 0, 0, 0);
-              dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16((bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]}, dsf,
-                                                            dq1, 0, 0, 0);
+            for (int ks = 0; ks < 7; ++ks) {
+              const BFrag cur = (ks & 1) ? fb : fa;
+              bmma(cur);
+              if (ks + 2 < 7) {
+                if (ks & 1) fb = bload(ks + 2);
+                else fa = bload(ks + 2);
+              }
             }
           }
-          const int q = qt * 16 + l15;
+          const int q = qt * 16 + l15o;
           const f32x4 v0_ = dq0 * p.scale, v1_ = dq1 * p.scale;
           u32x2 pa = {pack2bf(v0_[0], v0_[1]), pack2bf(v0_[2], v0_[3])};
           u32x2 pb = {pack2bf(v1_[0], v1_[1]), pack2bf(v1_[2], v1_[3])};
@@ -1893,18 +1929,19 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
             csq[0] += bf_round4(pa);
             csq[1] += bf_round4(pb);
           }
-          const int col = widen_pair(pa, pb, lg);
+          const int col = widen_pair(pa, pb, lgo);
           if (q < T)
             *(u32x4*)(p.dqkv + ((long)Hm.b * T + q) * ld + Hm.hh * DH + bd * 32 + col) = (u32x4){pa[0], pa[1], pb[0], pb[1]};
         }
       }
+      PIPE_ST(6)  // B(g-1) alone
       if (head_done) {  // dK, dV of this wave's key tiles of head hm; per-wave column sums of everything this wave stored
         f32x4 csk[ND], csv[ND];
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) csk[dt] = csv[dt] = zero4();
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
-          const int key = (rq ? kt1 : kt0) * 16 + l15;
+          const int key = (rq ? kt1 : kt0) * 16 + l15o;
           const bool okk = key < T;
           short* ok = p.dqkv + ((long)Hm.b * T + key) * ld + HD + Hm.hh * DH;
 #pragma unroll
@@ -1920,8 +1957,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
                 csv[dp * 2 + i] += bf_round4(pv[i]);
               }
             }
-            const int col = widen_pair(pk[0], pk[1], lg);
-            widen_pair(pv[0], pv[1], lg);
+            const int col = widen_pair(pk[0], pk[1], lgo);
+            widen_pair(pv[0], pv[1], lgo);
             if (okk) {
               *(u32x4*)(ok + dp * 32 + col) = (u32x4){pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
               *(u32x4*)(ok + HD + dp * 32 + col) = (u32x4){pv[0][0], pv[0][1], pv[1][0], pv[1][1]};
@@ -1935,8 +1972,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
             f32x4 tq_ = zero4();  // a B wave summed dQ over its two 16-column tiles only
             if (is_b && (dt >> 1) == bd) tq_ = rows16_sum(csq[dt & 1]);
             const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
-            const int d = dt * 16 + lg * 4;
-            if (l15 == 0) {
+            const int d = dt * 16 + lgo * 4;
+            if (l15o == 0) {
               *(f32x4*)(csum + d) = tq_;
               *(f32x4*)(csum + HD + d) = tk;
               *(f32x4*)(csum + 2 * HD + d) = tv;
@@ -1957,9 +1994,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     if (g == -2) {  // prologue: the first head's images, spread over the waves
       const int per = (kv_total + 7) >> 3;
       nissued += issue_KV(H2, 0, wave * per, per);
-    } else if (v0 && p0 >= 1 && h0 + 1 < nheads) {
+    } else if (is_d && v0 && p0 >= 1 && h0 + 1 < nheads) {
       if (p0 == 1) Hn = head_of(h0 + 1);
-      nissued += issue_KV(Hn, (h0 + 1) & 1, ((p0 - 1) * 8 + wave) * kvp, kvp);
+      nissued += issue_KV(Hn, (h0 + 1) & 1, ((p0 - 1) * 4 + wave) * kvp, kvp);
     }
     if (v2 && !(VIT_PIPE_SKIP & 4)) nissued += issue_L(H2, p2, (g + 2) % PIPE_NS);
     PIPE_ST(1)  // DMA issue
@@ -2054,12 +2091,12 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     if (v1 && is_d && !(VIT_PIPE_SKIP & 8)) {
       const int s1 = (g + 1) % PIPE_NS;
       const char* slot = ring + s1 * PIPE_SLOT;
-      const int rl = grp * 8 + rl8, ch = lane & 7;
+      const int rl = grp * 8 + rl8, ch = ln & 7;
       const bf16x8 d8 = *(const bf16x8*)(slot + 4096 + tile_off<DH>(rl, ch));
       const bf16x8 o8 = *(const bf16x8*)(slot + 8192 + rl * 128 + ch * 16);
       bf16x8 l8 = {0, 0, 0, 0, 0, 0, 0, 0};
       if (has_lo) l8 = *(const bf16x8*)(slot + 12288 + rl * 128 + ch * 16);
-      const float lraw = *(const float*)(lse_raw + (s1 * 4 + grp) * 256 + lane * 4);
+      const float lraw = *(const float*)(lse_raw + (s1 * 4 + grp) * 256 + ln * 4);
       float d_ = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(d8[e]);
