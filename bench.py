@@ -315,14 +315,23 @@ def main():
         gemm_fl = sum(v[2] for v in agg.values())
         # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 around the process);
         # it is the figure from the newest committed PMC passes of this same command, and `traffic_source` says which
+        # A counter file is only quoted when it was collected from THIS library: the summary records the sha256 of the kernel
+        # sources (`lib_stamp`, vit_amd.build.source_stamp()); a file from other kernels is refused and named as stale.
         traffic, traffic_source = None, None
         try:
             import glob
+
+            from vit_amd.build import source_stamp
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1:]:
-                ent = json.load(open(path))["kernels"].get(var)
-                if ent and args.workload == "vit_b16_224" and B == 256:
+                doc = json.load(open(path))
+                ent = doc["kernels"].get(var)
+                name = f"profiles/{os.path.basename(path)}"
+                if doc.get("lib_stamp") != source_stamp():
+                    traffic_source = (f"{name} is STALE (collected from other kernel sources: lib_stamp "
+                                      f"{str(doc.get('lib_stamp'))[:12]} != {source_stamp()[:12]}); not quoted")
+                elif ent and args.workload == "vit_b16_224" and B == 256:
                     traffic = ent["hbm_bytes_per_launch"]
-                    traffic_source = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc passes of this command, committed; constant, not re-measured here)"
+                    traffic_source = f"{name} (rocprofv3 --pmc passes of this command at the same kernel sources, committed; constant, not re-measured here)"
         except Exception:  # noqa: BLE001 - the profile summary is optional evidence, never required to run
             traffic = None
         roofline = {

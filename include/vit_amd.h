@@ -48,18 +48,13 @@ int vit_create(vit_handle* out, int device);
 int vit_destroy(vit_handle h);
 int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
 /* Process-wide tuning / diagnostics knobs (never change results beyond rounding order):
- *   "gemm_core": 0 = generic 128x128 core only, 1 = automatic (default); on tile-aligned problems 2 / 3 / 4 force the
- *                LDS-DMA core's 256x256xBK64 (2 stages) / 256x128xBK64 (3 stages) / 256x256xBK32 (4 stages) geometry,
- *                5 the 256x256xBK64 ping-pong variant (wave halves one barrier out of phase: LOAD segment beside MFMA
- *                segment, ring of 8 half-tiles, 4 in flight), 6 the 4-wave 256x128xBK32 (3 stages) geometry with two
- *                workgroups per CU.
+ *   "gemm_core": 0 = generic 128x128 core only, 1 = automatic (default): tile-aligned problems (M, N multiples of 256, K of
+ *                64) run the 256x256x64 ping-pong core (wave halves one barrier out of phase: LOAD segment beside MFMA
+ *                segment, ring of 8 half-tiles, 4 in flight); 5 = the same choice named explicitly.
  *   "attn_split": workgroups per (batch, head) in the resident attention kernels (T <= 256), default 2.
- *   "attn_bwd_fused": attention backward form: 3 (default) = the persistent pipelined single kernel where it fits (head_dim 64,
- *                T <= 224), else as 1; 1 / 2 = the fused single kernel with 8 / 16 waves (T <= 240); 0 = the dQ + dK/dV pair.
- *   "attn_debug": timing diagnostics for the fused kernels (bit 1 = no phase B, 2 = no phase A, 4 = no operand staging, 8 = no
- *                dK/dV stores, 16 / 32 (persistent form) = no K/V-row and delta-chunk loads / no lse loads and delta stores);
- *                results are meaningless while it is non-zero.  (Skipping phase A exposes the store-completion part of the
- *                s_waitcnt vmcnt(0) in front of the barriers, so the remainder over-states the non-compute time.)
+ *   "attn_bwd_fused": attention backward form: 4 (default) = the pair-pipelined single kernel where it fits (head_dim 64,
+ *                64 <= T <= 208), else as 3; 3 = the persistent single kernel (head_dim 64, T <= 224), else as 1; 1 / 2 = the
+ *                fused single kernel with 8 / 16 waves (T <= 240); 0 = the dQ + dK/dV pair.
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.
  *   "attn_res_max_t": longest sequence the resident attention kernels take (default 592 = what fits the LDS at head_dim
  *                64); longer ones, or everything with 0, go to the tiled kernels.
@@ -70,8 +65,8 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                (same makespan in tile-times, idle CUs instead of CUs that idle for the last round); 0 = always 256.
  *   "gemm_pp_slots": 8 (the only value since round 2: the 10-slot ring, 96 KiB of operand loads in flight per CU, measured
  *                0-15 % slower on the ViT-B shapes and was removed with the K-loop rewrite; any other value is VIT_ERR_ARG).
- *   "gemm_debug": timing diagnostics for the LDS-DMA core (1 = skip operand DMA after the prologue, 2 = skip MFMAs);
- *                results are meaningless while it is non-zero.
+ *   (Timing diagnostics that switch pieces of a kernel off are compile-time variant builds -- python -m vit_amd.build
+ *   --defs ... --tag ... -- never a switch of this library: results are meaningless in such a build.)
  *                Returns VIT_ERR_ARG for an unknown name. */
 int vit_set_option(const char* name, int value);
 

@@ -13,19 +13,21 @@ sys.path.insert(0, ROOT)
 import torch
 
 
-def main(out_dir, precision, exchange):
+def main(out_dir, precision, exchange, geom="C1", grad_dtype="fp32", max_bucket=0):
     from oracle import refvit  # checker-side helper: seeded weights / inputs only
     from vit_amd import ddp as ddp_mod
     from vit_amd.module import ViTLModule
     from vit_amd.trainer import Trainer, seed_everything
 
     seed_everything(42)
-    rc = refvit.named_config("C1")
+    rc = refvit.named_config(geom)  # "C3": ViT-B depth and widths -> 7.1 M-element (28 MB) layer buckets
+    nb = 8
     config = {
         "model": dict(name="vit", task_type="reg", image_size=rc.image_size, patch_size=rc.patch_size,
                       hidden_size=rc.hidden_size, num_hidden_layers=rc.num_hidden_layers,
                       num_attention_heads=rc.num_attention_heads, stride_size=rc.stride_size, proj_fn="SW"),
-        "train": dict(batch_size=8, ep=1, precision=precision, ddp_exchange=exchange),
+        "train": dict(batch_size=nb, ep=1, precision=precision, ddp_exchange=exchange, ddp_grad_dtype=grad_dtype,
+                      **({"ddp_max_bucket_elems": int(max_bucket)} if int(max_bucket) else {})),
         "loss": {"name": "mae"}, "opt": {"type": "AdamW", "lr": 1e-3}, "data": {"param": "log_g"}, "noise": {"noise_level": 0},
     }
     module = ViTLModule(config=config)
@@ -51,6 +53,9 @@ def main(out_dir, precision, exchange):
     torch.save({"grads": seen["grads"], "params": eng.flat.detach().cpu().clone(), "loss": float(loss), "idx": idx,
                 "n_trainable": eng.layout.n_trainable, "world": trainer.world, "backend": trainer.backend,
                 "mode": trainer.reducer.mode if trainer.reducer else None,
+                "calls": trainer.reducer.calls_per_step if trainer.reducer else 0,
+                "bytes": trainer.reducer.bytes_per_step if trainer.reducer else 0,
+                "overlap_dw": bool(eng.side_stream is not None),
                 "grad_norm": float(trainer.optimizer.last_grad_norm.sqrt())},
                os.path.join(out_dir, f"rank{trainer.rank}.pt"))
     if torch.distributed.is_initialized():
@@ -59,4 +64,4 @@ def main(out_dir, precision, exchange):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "allreduce")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "allreduce", *sys.argv[4:7])

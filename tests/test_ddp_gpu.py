@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = os.path.join(ROOT, "tests", "_ddp_child.py")
 
 
-def _run(tmp_path, world, precision, exchange, single_env=None):
+def _run(tmp_path, world, precision, exchange, single_env=None, extra=()):
     from vit_amd.launch import launch_ranks
 
-    out = tmp_path / f"w{world}_{precision}_{exchange}_{'rccl' if single_env else 'plain'}"
+    out = tmp_path / f"w{world}_{precision}_{exchange}_{'rccl' if single_env else 'plain'}_{'_'.join(map(str, extra))}"
     out.mkdir()
     env = {"VIT_DIST_BACKEND": "gloo"}
     if world == 1:
@@ -27,11 +27,11 @@ def _run(tmp_path, world, precision, exchange, single_env=None):
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VIT_DIST_SINGLE", "VIT_DIST_BACKEND"):
             e.pop(k, None)
         e.update(single_env or {})
-        r = subprocess.run([sys.executable, CHILD, str(out), precision, exchange], env=e, capture_output=True, text=True,
-                           timeout=600)
+        r = subprocess.run([sys.executable, CHILD, str(out), precision, exchange, *map(str, extra)], env=e, capture_output=True,
+                           text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
     else:
-        assert launch_ranks(world, CHILD, [str(out), precision, exchange], extra_env=env) == 0
+        assert launch_ranks(world, CHILD, [str(out), precision, exchange, *map(str, extra)], extra_env=env) == 0
     return [torch.load(out / f"rank{r}.pt", weights_only=True) for r in range(world)]
 
 
@@ -115,3 +115,37 @@ def test_checkpoint_resume_under_exchange(tmp_path, exchange):
     assert torch.equal(r[0]["full"]["params"], r[1]["full"]["params"])
     # the saved moments themselves were complete (rank 0's file): nothing of the other rank's shard left at zero
     assert float((r[0]["part"]["m"] != 0).float().mean()) > 0.9
+
+
+def test_two_ranks_at_vit_b_geometry(tmp_path):
+    """the N > 1 path at the BENCHMARKED geometry (12 x 768, T = 197: C3 / C4), four samples per rank, two
+    ranks sharing the GPU over gloo, bf16-mixed with the weight-gradient GEMMs on the second stream: the 14 buckets are the real
+    ones (7.1 M elements = 28 MB per layer), the exchange is handed over from the side stream (engine._notify), a forced
+    1 M-element limit splits every layer bucket into 7 collectives (ddp.py: max_bucket_elems), and 'zero1' shards at that size.
+    All of them must leave the replicas bit-identical and agree with the single-process run on the full batch; the optional
+    bf16 exchange is measured against the fp32 one (it rounds each rank's gradient to 8 bits before the sum)."""
+    single = _run(tmp_path, 1, "bf16-mixed", "allreduce", extra=("C3",))[0]
+    two = _run(tmp_path, 2, "bf16-mixed", "allreduce", extra=("C3",))
+    n = single["n_trainable"]
+    assert two[0]["world"] == 2 and two[0]["calls"] == 14 and two[0]["bytes"] == 4 * n and two[0]["overlap_dw"]
+    assert torch.equal(two[0]["grads"][:n], two[1]["grads"][:n]) and torch.equal(two[0]["params"], two[1]["params"])
+    g1, g2 = single["grads"][:n].double(), two[0]["grads"][:n].double()
+    e = float((g1 - g2).norm() / g1.norm())
+    assert e < 2e-2, e
+    assert abs(two[0]["grad_norm"] - single["grad_norm"]) <= 2e-2 * single["grad_norm"]
+    # forced split: same values, more collectives
+    split = _run(tmp_path, 2, "bf16-mixed", "allreduce", extra=("C3", "fp32", 1 << 20))
+    assert split[0]["calls"] > 14 * 6
+    assert torch.equal(split[0]["grads"][:n], two[0]["grads"][:n]) and torch.equal(split[0]["params"], two[0]["params"])
+    # sharded schedule at size: bit-identical parameters to the all-reduce
+    z = _run(tmp_path, 2, "bf16-mixed", "zero1", extra=("C3",))
+    assert z[0]["mode"] == "zero1" and torch.equal(z[0]["params"], z[1]["params"])
+    # same parameters as the all-reduce up to the rounding of the clipping norm (summed shard by shard here, in one pass there)
+    assert abs(z[0]["grad_norm"] - two[0]["grad_norm"]) <= 1e-5 * two[0]["grad_norm"]
+    assert float((z[0]["params"][:n] - two[0]["params"][:n]).abs().max()) < 1e-6
+    # bf16 exchange: half the bytes; its cost against the fp32 exchange, per gradient tensor norm
+    b = _run(tmp_path, 2, "bf16-mixed", "allreduce", extra=("C3", "bf16"))
+    assert b[0]["bytes"] == 2 * n and torch.equal(b[0]["grads"][:n], b[1]["grads"][:n])
+    eb = float((b[0]["grads"][:n].double() - g2).norm() / g2.norm())
+    print(f"[ddp C3] 2-rank vs single grad rel err {e:.2e}; bf16 exchange vs fp32 exchange {eb:.2e}")
+    assert 1e-4 < eb < 6e-3, eb

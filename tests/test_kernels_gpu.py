@@ -361,7 +361,7 @@ ALIGNED = [(256, 128, 64), (256, 256, 64), (512, 256, 128), (512, 512, 192), (10
            (1792, 2304, 768)]
 
 
-@pytest.mark.parametrize("core", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("core", [5])
 @pytest.mark.parametrize("M,N,K", ALIGNED)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
 def test_gemm2_layouts(dev, core, M, N, K, layout):
@@ -385,7 +385,7 @@ def test_gemm2_layouts(dev, core, M, N, K, layout):
     assert rel(sk, ref) < 2e-5
 
 
-@pytest.mark.parametrize("core", [0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("core", [0, 5])
 def test_gemm2_epilogues_match_generic_core(dev, core):
     """Every fused epilogue on a tile-aligned problem, each core against the torch reference (and so against each other)."""
     import vit_amd.functional as vf
@@ -599,7 +599,7 @@ def test_gemm_colsum_out(dev, core):
         _cabi.set_option("gemm_core", 1)
 
 
-@pytest.mark.parametrize("core", [0, 1, 2])
+@pytest.mark.parametrize("core", [0, 1, 5])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_gemm_gelu_grad_and_mul_aux(dev, core, dt):
     """ACT_GELU_GRAD saves gelu'(pre-activation) in the forward, ACT_MUL_AUX multiplies by it in the backward: together they

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMM microbenchmark over the ViT-B/16 (C3) shapes: every GEMM of one layer's forward + backward, each GEMM core
-(0 = generic 128x128 register-staged; LDS-DMA core: 2 = 256x256xBK64x2, 3 = 256x128xBK64x3, 4 = 256x256xBK32x4), interleaved rounds in ONE process, random data.
+(0 = generic 128x128 register-staged, 5 = the 256x256x64 ping-pong LDS-DMA core), interleaved rounds in ONE process, random data.
 Usage: python tools/gemm_bench.py [--rounds 5] [--cores 0,2,3]"""
 import argparse
 import os
@@ -17,7 +17,7 @@ from vit_amd._cabi import ACT_DGELU, ACT_GELU
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--cores", default="0,2,6")
+    ap.add_argument("--cores", default="0,5")
     ap.add_argument("--M", type=int, default=50432)
     args = ap.parse_args()
     cores = [c for c in args.cores.split(",")]  # "5" or "5s8" / "5s10": ping-pong core with an 8- / 10-slot ring

@@ -11,6 +11,8 @@
 
 usage: python tools/pmc_kernels.py OUT.json DIR [DIR ...] [--match substring] [--cus 256]"""
 import csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vit_amd.build import source_stamp
 from collections import defaultdict
 
 
@@ -33,7 +35,7 @@ def main():
     doc = {"source": "rocprofv3 --kernel-trace --pmc <counters> (one pass per directory: " + ", ".join(dirs) + ")",
            "corrections": "FETCH_SIZE doubled (gfx950 half-counts wide coalesced reads), WRITE_SIZE exact, both KiB; SQ_* "
                           "wave-cycle counters are quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md)",
-           "kernels": {}}
+           "lib_stamp": source_stamp(), "kernels": {}}
     for name in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("GRBM_GUI_ACTIVE", 0))):
         c = {k: acc[name][k] / cnt[name][k] for k in acc[name]}
         e = {"launches": max(cnt[name].values()), "counters": {k: round(v, 1) for k, v in sorted(c.items())}}

@@ -58,16 +58,16 @@ cases["NT fc1 fwd +gelu,aux N=3072"] = (lambda: vf.gemm(x768, W1, M=M, N=F, K=D,
 cases["NN dX fc2 *aux N=3072 K=768"] = (lambda: vf.gemm(dy768, W2, M=M, N=F, K=D, b_trans=True, act=_cabi.ACT_MUL_AUX, aux_in=aux, out=o3072), 2 * M * F * D)
 print("kernel:", end=" ")
 for name, (fn, fl) in cases.items():
-    _cabi.set_option("gemm_debug", 0)
+    _cabi.load().vit_debug_pp_diag(0)
     fn()
     print(_cabi.load().vit_last_gemm_kernel().decode(), end="; ")
 print()
 for name, (fn, fl) in cases.items():
     row = []
     for m, label in masks:
-        _cabi.set_option("gemm_debug", m)
+        _cabi.load().vit_debug_pp_diag(m)
         us = t(fn)
         row.append(f"{label} {us:6.1f}")
     full = float(row[0].split()[-1])
     print(f"{name} [{fl / full / 1e6:5.0f} TF] " + " | ".join(row), flush=True)
-_cabi.set_option("gemm_debug", 0)
+_cabi.load().vit_debug_pp_diag(0)

@@ -41,6 +41,12 @@ def _stamp(paths) -> str:
     return h.hexdigest()
 
 
+def source_stamp() -> str:
+    """sha256 over the library's sources (what `build()` compares against to decide whether to rebuild): profile summaries
+    record it (tools/pmc_traffic.py, tools/pmc_kernels.py) so that a reader can tell which kernels a counter set belongs to."""
+    return _stamp([os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)])
+
+
 def _torch_libdir() -> str:
     import torch
 

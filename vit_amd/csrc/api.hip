@@ -15,8 +15,8 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode, g_gemm2_debug, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
-extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_debug;  // attention.hip
+extern int g_gemm2_mode, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
+extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused;  // attention.hip
 
 static thread_local char g_err[512] = "";
 thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
@@ -90,17 +90,15 @@ const char* vit_last_gemm_kernel(void) { return vit::g_last_gemm; }
 int vit_set_option(const char* name, int value) {
   VIT_CHECK(name, VIT_ERR_ARG, "vit_set_option: null name");
   if (strcmp(name, "gemm_core") == 0) {
-    VIT_CHECK(value >= 0 && value <= 6, VIT_ERR_ARG, "vit_set_option: gemm_core must be 0..6");
+    VIT_CHECK(value == 0 || value == 1 || value == 5, VIT_ERR_ARG,
+              "vit_set_option: gemm_core must be 0 (generic core), 1 (automatic) or 5 (ping-pong core; what 1 selects on aligned "
+              "problems); the lock-step geometries 2 / 3 / 4 / 6 were removed in round 3");
     vit::g_gemm2_mode = value;
     return VIT_OK;
   }
   if (strcmp(name, "attn_split") == 0) {
     if (value < 1 || value > 8) return VIT_ERR_ARG;
     vit::g_attn_split = value;
-    return VIT_OK;
-  }
-  if (strcmp(name, "attn_debug") == 0) {
-    vit::g_attn_debug = value;
     return VIT_OK;
   }
   if (strcmp(name, "attn_bwd_fused") == 0) {
@@ -128,10 +126,6 @@ int vit_set_option(const char* name, int value) {
     vit::g_pp_slots = value;
     return VIT_OK;
   }
-  if (strcmp(name, "gemm_debug") == 0) {  // timing diagnostics of the LDS-DMA core; results are meaningless when set
-    vit::g_gemm2_debug = value;
-    return VIT_OK;
-  }
   vit::set_error("vit_set_option: unknown option '%s'", name);
   return VIT_ERR_ARG;
 }
@@ -153,6 +147,14 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes) {
 
 }  // extern "C"
 
+#ifdef VIT_PP_DIAG
+// diagnostic twin build only (python -m vit_amd.build --diag; tools/pp_diag.py): switch pieces of the ping-pong K loop off
+namespace vit { extern int g_gemm2_debug; }
+extern "C" int vit_debug_pp_diag(int bits) {
+  vit::g_gemm2_debug = bits;
+  return 0;
+}
+#endif
 #ifdef VIT_PP_STAMP
 // diagnostic build only (python -m vit_amd.build --stamps N): where gemm3_kernel's workgroup `block` spends its cycles
 namespace vit { extern unsigned long long* g_pp_stamps; extern int g_pp_stamp_block; }

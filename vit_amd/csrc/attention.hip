@@ -25,6 +25,12 @@ namespace vit {
 
 void* ctx_workspace(vit_handle h, size_t* bytes);
 
+// Timing variants of the fused / persistent backward kernels are COMPILE-TIME builds (python -m vit_amd.build --defs
+// -DVIT_ATTN_SKIP=n --tag name; bits: 1 no phase B, 2 no phase A, 4 no operand staging, 8 no dK/dV stores, 16 / 32 (persistent
+// form) no K/V-row and delta-chunk loads / no lse loads and delta stores); the product library has no such switch.
+#ifndef VIT_ATTN_SKIP
+#define VIT_ATTN_SKIP 0
+#endif
 constexpr int AW = 4;    // waves per workgroup
 constexpr int RT = 64;   // rows per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -40,7 +46,6 @@ struct AttnArgs {
   float scale;
   DropCfg drop;
   int nsplit, wpw;  // resident kernels: workgroups per (batch, head) and waves per workgroup (row tiles are dealt in order)
-  int dbg;           // timing diagnostics for the fused backward (vit_set_option("attn_debug")): skip pieces; results invalid
   float* csum_part;  // resident backward kernels: [B * nsplit * wpw][3 * H * dh] per-wave column sums of dqkv as stored, or NULL
 };
 
@@ -567,6 +572,26 @@ __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, i
   }
 }
 
+// Two adjacent 16-column tiles of one 16-row block, packed to bf16 (a lane holds 4 consecutive columns of each: 8 bytes + 8
+// bytes), into ONE 16-byte store per lane: v_permlane16_swap trades the odd lane groups' first-tile data for the even
+// groups' second-tile data, so an even group ends with 8 consecutive columns of the first tile, an odd group with 8 of the
+// second.  Row-per-lane stores are issue-bound (each instruction touches 16 rows): half the instructions, half the time.
+// Returns this lane's first column within the 32-column pair.
+__device__ __forceinline__ int widen_pair(u32x2& a, u32x2& b, int lg) {
+  auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  a[0] = r0[0]; b[0] = r0[1];
+  a[1] = r1[0]; b[1] = r1[1];
+  return (lg & 1) ? 16 + 4 * (lg - 1) : 4 * lg;
+}
+
+// lo = bf16(v - bf16(v)) for 4 values already packed as pk (the context residual), returned packed
+__device__ __forceinline__ u32x2 pack_lo(const f32x4& v, const u32x2& pk) {
+  const float h0 = __builtin_bit_cast(float, pk[0] << 16), h1 = __builtin_bit_cast(float, pk[0] & 0xFFFF0000u);
+  const float h2 = __builtin_bit_cast(float, pk[1] << 16), h3 = __builtin_bit_cast(float, pk[1] & 0xFFFF0000u);
+  return (u32x2){pack2bf(v[0] - h0, v[1] - h1), pack2bf(v[2] - h2, v[3] - h3)};
+}
+
 template <int DH, int RQ>
 __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
@@ -670,14 +695,19 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
 #pragma unroll
       for (int i = 0; i < DH / 16; ++i) ot[rq][i] *= alpha;
       if (p.drop.thr) {
-        const unsigned long long drow = (unsigned long long)bh * T + (q00 + rq * 16 + l15);
+        // keep <=> the element's 16-bit draw >= thr: the high draw by ONE unsigned compare of the whole word against thr << 16,
+        // the low draw after one shift; dropped probabilities become 0 by a select, and the 1 / (1 - p) of the kept ones is
+        // applied once per row at the end (it rides in `inv`): 2.5 instead of 4 VALU per element in this VALU-bound kernel
+        const unsigned rkey = drop_rowkey(p.drop, (unsigned long long)bh * T + (q00 + rq * 16 + l15));
+        const unsigned thr16 = p.drop.thr << 16;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const unsigned key = kb + j * 16 + lg * 4;
-          float k0, k1, k2, k3;
-          drop_pair(p.drop, drow, half_cols, key, k0, k1);
-          drop_pair(p.drop, drow, half_cols, key + 2, k2, k3);
-          st[rq][j][0] *= k0; st[rq][j][1] *= k1; st[rq][j][2] *= k2; st[rq][j][3] *= k3;
+          const unsigned ha = drop_bits(rkey, key >> 1), hb = drop_bits(rkey, (key >> 1) + 1);
+          st[rq][j][0] = (ha << 16) >= thr16 ? st[rq][j][0] : 0.f;
+          st[rq][j][1] = ha >= thr16 ? st[rq][j][1] : 0.f;
+          st[rq][j][2] = (hb << 16) >= thr16 ? st[rq][j][2] : 0.f;
+          st[rq][j][3] = hb >= thr16 ? st[rq][j][3] : 0.f;
         }
       }
     }
@@ -714,9 +744,23 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
   for (int rq = 0; rq < RQ; ++rq) {
     const float lt = grp4_sum(l[rq]);
     const int q = q00 + rq * 16 + l15;
-    if (q < T) {
-      const float inv = 1.0f / lt;
-      short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
+    const float inv = (p.drop.thr ? p.drop.scale : 1.0f) / lt;  // the kept probabilities' 1 / (1 - p) rides here
+    short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
+    if (dh == DH && (DH % 32) == 0) {
+      // 16-byte stores: two adjacent 16-column tiles per instruction (row-per-lane stores are issue-bound)
+#pragma unroll
+      for (int dp = 0; dp < DH / 32; ++dp) {
+        const f32x4 v0 = ot[rq][dp * 2] * inv, v1 = ot[rq][dp * 2 + 1] * inv;
+        u32x2 p0 = {pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3])}, p1 = {pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3])};
+        u32x2 l0 = pack_lo(v0, p0), l1 = pack_lo(v1, p1);
+        const int col = widen_pair(p0, p1, lg);
+        widen_pair(l0, l1, lg);
+        if (q < T) {
+          *(u32x4*)(o + dp * 32 + col) = (u32x4){p0[0], p0[1], p1[0], p1[1]};
+          if (p.ctx_lo) *(u32x4*)(p.ctx_lo + (o - p.ctx) + dp * 32 + col) = (u32x4){l0[0], l0[1], l1[0], l1[1]};
+        }
+      }
+    } else if (q < T) {
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
         const int d = dt * 16 + lg * 4;
@@ -727,8 +771,8 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
           if (p.ctx_lo) store_lo(p.ctx_lo + (o - p.ctx) + d, v, pk);
         }
       }
-      if (lg == 0) p.lse[(long)bh * T + q] = (m[rq] * c + log2f(lt)) * LN2;
     }
+    if (q < T && lg == 0) p.lse[(long)bh * T + q] = (m[rq] * c + log2f(lt)) * LN2;
   }
 }
 
@@ -1162,7 +1206,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
       if (p.ctx_lo) ol[it] = *(const i32x4*)(p.ctx_lo + (ob - p.ctx) + (long)row * ldc + dch * 8);
     }
   }
-  if (!(p.dbg & 4)) load_all_tiles3<DH>(Qimg, qb, ld, Oimg, dob, ldc, Kimg, kb_, ld, T, dh, R, tid, NW * 64);
+  if (!(VIT_ATTN_SKIP & 4)) load_all_tiles3<DH>(Qimg, qb, ld, Oimg, dob, ldc, Kimg, kb_, ld, T, dh, R, tid, NW * 64);
   __syncthreads();
   // ---- delta[q] = sum_d dO[q,d] (O[q,d] + O_lo[q,d]), lse in the exp2 domain
 #pragma unroll
@@ -1200,7 +1244,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
     const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
     if (pp0 >= npairs) break;  // uniform over the workgroup
     // ------------------------------------------------------------------ phase A: this wave's keys x the half's queries
-    if (k00 < R && !(p.dbg & 2)) {
+    if (k00 < R && !(VIT_ATTN_SKIP & 2)) {
       for (int pp = pp0; pp < pp1; ++pp) {
         const int qb0 = pp * 32;
         const char* Qt = Qimg + (qb0 >> 6) * TILE;
@@ -1269,7 +1313,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
     __syncthreads();
     // ------------------------------------------------------------------ phase B: dQ of query tile (2 pp0 + wave) over all keys
     const int qt = pp0 * 2 + wave / WPQ, dt0 = (wave % WPQ) * DPW;
-    if (qt < nq && qt < pp1 * 2 && !(p.dbg & 1)) {
+    if (qt < nq && qt < pp1 * 2 && !(VIT_ATTN_SKIP & 1)) {
       f32x4 dqt[DPW];
 #pragma unroll
       for (int i = 0; i < DPW; ++i) dqt[i] = zero4();
@@ -1317,7 +1361,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
     const int key = k00 + rq * 16 + l15;
-    if (key < T && !(p.dbg & 8)) {
+    if (key < T && !(VIT_ATTN_SKIP & 8)) {
       short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * dh + h * dh;
       short* ov = ok + p.H * dh;
 #pragma unroll
@@ -1390,16 +1434,16 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
   auto qoff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ld + (long)(bh - b * p.H) * DH; };
   auto coff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ldc + (long)(bh - b * p.H) * DH; };
   auto issue_half = [&](char* buf, int bh, int half) {
-    if (!(p.dbg & 4)) {
+    if (!(VIT_ATTN_SKIP & 4)) {
       dma_rows64(buf, p.qkv + qoff_of(bh), ld, half * 128, 128, T, wave, lane);
       dma_rows64(buf + HALFB, p.dctx + coff_of(bh), ldc, half * 128, 128, T, wave, lane);
     }
   };
   auto issue_k = [&](int bh) {
-    if (!(p.dbg & 4)) dma_rows64(Kimg, p.qkv + qoff_of(bh) + HD, ld, 0, R, T, wave, lane);
+    if (!(VIT_ATTN_SKIP & 4)) dma_rows64(Kimg, p.qkv + qoff_of(bh) + HD, ld, 0, R, T, wave, lane);
   };
   auto issue_regs = [&](int bh) {  // this wave's K / V rows of head bh
-    if (p.dbg & 16) return;
+    if (VIT_ATTN_SKIP & 16) return;
     const short* kb_ = p.qkv + qoff_of(bh) + HD;
 #pragma unroll
     for (int rq = 0; rq < RQ; ++rq) {
@@ -1419,7 +1463,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
     for (int i = 0; i < 2; ++i) {
       const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
       o4[i] = d4[i] = l4[i] = (i32x4){0, 0, 0, 0};
-      if (row < T && row < row_hi && !(p.dbg & 16)) {
+      if (row < T && row < row_hi && !(VIT_ATTN_SKIP & 16)) {
         const long e0 = co + (long)row * ldc + dch * 8;
         o4[i] = *(const i32x4*)(p.ctx + e0);
         d4[i] = *(const i32x4*)(p.dctx + e0);
@@ -1434,7 +1478,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
-      lsev[i] = (row < T && row < row_hi && !(p.dbg & 32)) ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
+      lsev[i] = (row < T && row < row_hi && !(VIT_ATTN_SKIP & 32)) ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1449,7 +1493,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
         st[R + row] = row < T ? d_ : 0.f;
         st[row] = lsev[i];
         ((unsigned*)st)[2 * R + row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
-        if (row < T && !(p.dbg & 32)) p.delta[(long)bh * T + row] = d_;
+        if (row < T && !(VIT_ATTN_SKIP & 32)) p.delta[(long)bh * T + row] = d_;
       }
     }
   };
@@ -1493,10 +1537,10 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
       // The prefetch is issued AFTER the first query pair of phase A (or here, by a wave that has no phase A): the first MFMA of
       // phase A needs the K / V rows that came by global loads, for which the compiler can only write s_waitcnt vmcnt(0) --
       // with the LDS-DMA already in flight that wait drained the prefetch it was meant to overlap (369 -> 362 us).
-      const bool in_a = k00 < R && !(p.dbg & 2) && pp0 < pp1;
+      const bool in_a = k00 < R && !(VIT_ATTN_SKIP & 2) && pp0 < pp1;
       if (!in_a) prefetch_next();
       // ------------------------------------------------------------------ phase A
-      if (k00 < R && !(p.dbg & 2)) {
+      if (k00 < R && !(VIT_ATTN_SKIP & 2)) {
         const float kinf[RQ] = {(k00 + l15 < T) ? 0.f : INFINITY, (k00 + 16 + l15 < T) ? 0.f : INFINITY};
         for (int pp = pp0; pp < pp1; ++pp) {
           const int qb0 = pp * 32, ql = (pp - pp0) * 32;  // global / buffer-local first query row of the pair
@@ -1576,7 +1620,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
         f32x4 dqt[DH / 16];
 #pragma unroll
         for (int i = 0; i < DH / 16; ++i) dqt[i] = zero4();
-        const bool have = qt < nq && qt < pp1 * 2 && !(p.dbg & 1);
+        const bool have = qt < nq && qt < pp1 * 2 && !(VIT_ATTN_SKIP & 1);
         if (have) {
           const int tq = l15 >> 2, tp = l15 & 3;
           const char* dcol = dSimg + ds_off(4 * lg + tq, wave * 4 + tp);
@@ -1617,7 +1661,7 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) {
           const int key = k00 + rq * 16 + l15;
-          if (key < T && !(p.dbg & 8)) {
+          if (key < T && !(VIT_ATTN_SKIP & 8)) {
             short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * DH + h * DH;
             short* ov = ok + p.H * DH;
 #pragma unroll
@@ -1739,19 +1783,6 @@ __device__ unsigned long long g_pipe_st[8 * 8];
 #else
 #define PIPE_ST(K)
 #endif
-
-// Two adjacent 16-column tiles of one 16-row block, packed to bf16 (a lane holds 4 consecutive columns of each: 8 bytes + 8
-// bytes), into ONE 16-byte store per lane: v_permlane16_swap trades the odd lane groups' first-tile data for the even
-// groups' second-tile data, so an even group ends with 8 consecutive columns of the first tile, an odd group with 8 of the
-// second.  Row-per-lane stores are issue-bound (each instruction touches 16 rows): half the instructions, half the time.
-// Returns this lane's first column within the 32-column pair.
-__device__ __forceinline__ int widen_pair(u32x2& a, u32x2& b, int lg) {
-  auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-  auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-  a[0] = r0[0]; b[0] = r0[1];
-  a[1] = r1[0]; b[1] = r1[1];
-  return (lg & 1) ? 16 + 4 * (lg - 1) : 4 * lg;
-}
 
 struct PipeHead { int bh, b, hh; };
 
@@ -2145,7 +2176,6 @@ static bool persist_fits(int T, int dh) {
   return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24) <= 160 * 1024;
 }
 
-int g_attn_debug = 0;
 // vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent form where it fits
 // (dh 64, T <= 224), 4 (default) = the pair-pipelined form where it fits (dh 64, 64 <= T <= 208), else 3, else 1
 int g_attn_bwd_fused = 4;
@@ -2500,7 +2530,6 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop_h(h, dropout_p, seed, site);
   a.csum_part = colsum_part;
-  a.dbg = g_attn_debug;
   if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
     const size_t rows = (T + 15) & ~15;
     const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 12);

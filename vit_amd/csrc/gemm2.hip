@@ -1,25 +1,26 @@
-// Second-generation bf16 MFMA GEMM core for gfx950, used when the problem is tile-aligned (the ViT-B / ViT-L shapes
-// are: M = B*T = 197*256, N and K multiples of 256 / 64).  Same contract, operand layouts, MFMA operand maps and fused
-// epilogues as gemm.hip; what changes is how operands reach the LDS, how long they may be in flight, and how results
-// leave the CU:
+// Ping-pong bf16 MFMA GEMM core for gfx950, used when the problem is tile-aligned (the ViT-B / ViT-L shapes are: M = B*T
+// padded to 256 rows, N multiples of 256, K multiples of 64).  Same contract, operand layouts, MFMA operand maps and fused
+// epilogues as gemm.hip; what changes is how operands reach the LDS, how long they may be in flight, and how results leave
+// the CU:
 //
-//   * 256-row tiles (256x256 or 256x128), 8 waves = 512 threads, one workgroup per CU;
-//   * LDS-DMA staging: __builtin_amdgcn_global_load_lds(.., 16, ..) writes 1 KiB per wave-instruction straight into a
-//     ring of NSTAGE stages, no staging registers.  The DMA destination is lane-linear, so the XOR swizzle of both
+//   * 256x256x64 tiles, 8 waves = 512 threads, one workgroup per CU; the two wave halves run one barrier out of phase
+//     (LOAD segment beside MFMA segment): gemm3_kernel below; gemm3h_kernel takes the tiles of a partial last round;
+//   * LDS-DMA staging (global_load_lds_dwordx4 by inline asm, common.h: lds_dma16): 1 KiB per wave-instruction straight into
+//     a ring of 8 half-tile slots, no staging registers.  The DMA destination is lane-linear, so the XOR swizzle of both
 //     image kinds is applied to the per-lane SOURCE address and to the fragment reads (never to the destination);
-//   * counted waits: K-tile `it` is awaited with s_waitcnt vmcnt((NSTAGE-2) * loads_per_tile) + one raw s_barrier per
-//     K-tile, so NSTAGE-1 K-tiles stay in flight across barriers (measured: with one tile in flight the waves sat in
-//     s_waitcnt ~50 % of the time).  Default geometry BK = 32, 4 stages: 3 K-tiles = 96 KiB in flight per CU;
+//   * counted waits (s_waitcnt vmcnt(N), raw s_barrier): four half-tiles = 64 KiB stay in flight across barriers and across
+//     output-tile boundaries;
 //   * persistent over output tiles: a workgroup walks its tiles in one flat (tile, k-tile) iteration space, so the
 //     loads of the next tile's first K-tiles are already in flight during the current tile's epilogue;
 //   * XCD-aware tile order inside each round of concurrently running tiles (neighbours in n share the A panel in L2);
-//   * epilogue through a per-wave LDS transpose (the 32 KiB / 16 KiB the ring leaves free): accumulators go to LDS in
-//     MFMA layout and come back row-major, so every bias / aux / residual load and every output store of a
-//     wave-instruction covers whole 128- or 256-byte row segments instead of 16 rows x 32 bytes.
+//   * epilogue through a per-wave LDS transpose (the 32 KiB the ring leaves free): accumulators go to LDS in MFMA layout and
+//     come back row-major, so every bias / aux / residual load and every output store of a wave-instruction covers whole
+//     128- or 256-byte row segments instead of 16 rows x 32 bytes.
+// (The earlier lock-step geometries -- 256x256 / 256x128, 2-4 stage rings, selectable as gemm_core 2 / 3 / 4 / 6 -- were never
+// chosen automatically once the ping-pong form existed and were removed in round 3.)
 //
 // LDS images (byte offsets inside one operand image of R rows):
 //   K-contiguous, BK=64: row r, 16-B chunk c at r*128 + ((c ^ ((r>>1)&7)) << 4)
-//   K-contiguous, BK=32: row r, 16-B chunk c at r*64  + ((c ^ ((-(r>>2))&3)) << 4)
 //   transposed:          k-row k, 8-B chunk ch at k*2R + ((ch ^ tr_swz(k)) << 3),  tr_swz(k) = ((k&3) | ((k>>3)&1)<<2) << 2
 // all conflict-free for the 16x16x32 operand reads (ds_read_b128 / ds_read_b64_tr_b16): SQ_LDS_BANK_CONFLICT = 0.
 #include <algorithm>
@@ -45,7 +46,9 @@ struct Gemm2Args {
   int act, c_dtype;
   DropCfg drop;
   int rpb, orb, roff;
-  int debug;  // diagnostics only (vit_set_option "gemm_debug"): 1 = no DMA after the prologue, 2 = no MFMA
+#ifdef VIT_PP_DIAG
+  int debug;  // diagnostic twin build only (python -m vit_amd.build --diag, tools/pp_diag.py): pieces of the K loop switched off
+#endif
   int lin_split;  // ping-pong kernel, split-K with one tile per workgroup: 1-D grid of tiles x splits, XCD-contiguous
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
   int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
@@ -58,28 +61,6 @@ struct Gemm2Args {
 };
 
 __device__ __forceinline__ int tr_swz2(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 2; }
-
-// per-thread DMA source offset (elements) of round i for one operand image (NW waves issue NW KiB per round);
-// destination = i*NW*1024 + wave*1024 + lane*16
-template <int TRANS, int R, int BK, int NW>
-__device__ __forceinline__ int dma_src_off(int i, int wave, int lane, int ld) {
-  if (TRANS == 0) {
-    if (BK == 64) {
-      const int row = i * (NW * 8) + wave * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      return row * ld + c * 8;
-    } else {
-      const int row = i * (NW * 16) + wave * 16 + (lane >> 2);
-      const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
-      return row * ld + c * 8;
-    }
-  } else {
-    constexpr int RB = R * 2, LPR = RB / 16;
-    const int k = i * (NW * 1024 / RB) + wave * (1024 / RB) + lane / LPR;
-    const int c16 = (lane % LPR) ^ (tr_swz2(k) >> 1);
-    return k * ld + c16 * 8;
-  }
-}
 
 // Epilogue of one wave's (WM*16) x (WN*16) accumulator tile through its private LDS scratch (see file header).
 template <int WM, int WN, int CW, int EPI>
@@ -164,173 +145,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[WM][WN], char* scr, c
   }
 }
 
-// EPI: 0 = alpha/bias/dropout/residual/row-map (runtime flags), 1 = + erf-GELU (+ pre-activation save), 2 = * gelu'(aux)
-// NW = 8: one 512-thread workgroup per CU (160 KiB LDS); NW = 4: two independent 256-thread workgroups per CU (80 KiB
-// each), so one workgroup's epilogue / DMA waits overlap the other's MFMAs.
-template <int BM, int BN, int BK, int NSTAGE, int NW, int A_T, int B_T, int EPI>
-__global__ __launch_bounds__(NW * 64, 2) void gemm2_kernel(Gemm2Args p) {
-  resolve_drop(p.drop);
-  constexpr int WAVES_N = (NW == 8 && BN == 256) ? 4 : 2, WAVES_M = NW / WAVES_N;
-  constexpr int LDS_TOTAL = (NW == 8) ? 160 * 1024 : 80 * 1024;
-  constexpr int RND = NW * 1024;  // bytes one DMA round (one instruction per wave) moves
-  constexpr int WM = BM / WAVES_M / 16, WN = BN / WAVES_N / 16;
-  constexpr int KS = BK / 32;  // MFMA k-steps per K-tile
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int GA = A_BYTES / RND, GB = B_BYTES / RND, G = GA + GB;  // LDS-DMA instructions per thread per K-tile
-  constexpr int RING = NSTAGE * STAGE;
-  constexpr int SCR = (LDS_TOTAL - RING) / NW;         // epilogue scratch per wave: 4 KiB or 2 KiB
-  constexpr int CW = SCR / 64;                          // columns per epilogue chunk (16 rows x CW f32): 64 or 32
-  static_assert(SCR == 4096 || SCR == 2048, "ring + epilogue scratch must fill the workgroup's LDS share");
-  static_assert((WN * 16) % CW == 0, "wave tile width must be a multiple of the epilogue chunk");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int l15 = lane & 15, lg = lane >> 4;
-
-  const int split = blockIdx.y;
-  const int k_begin = split * p.k_per_split;
-  const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int nk = (k_end - k_begin) / BK;
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int bx = blockIdx.x, nblk = p.nblk;
-  const int my_tiles = (ntile - bx + nblk - 1) / nblk;
-  const int total_it = my_tiles * nk;
-
-  int offA[GA], offB[GB];
-#pragma unroll
-  for (int i = 0; i < GA; ++i) offA[i] = dma_src_off<A_T, BM, BK, NW>(i, wave, lane, (int)p.lda);
-#pragma unroll
-  for (int i = 0; i < GB; ++i) offB[i] = dma_src_off<B_T, BN, BK, NW>(i, wave, lane, (int)p.ldb);
-
-  // tile index of this block's j-th tile: XCD-aware remap inside each round of nblk concurrently running tiles
-  auto tile_coords = [&](int j, int& tm, int& tn) {
-    const int round0 = j * nblk;
-    const int n_here = min(nblk, ntile - round0);
-    const int q = n_here >> 3, r = n_here & 7, xcd = bx & 7, within = bx >> 3;
-    int pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    if (p.debug & 4) pos = bx;            // diagnostics: no XCD remap
-    const int t = round0 + pos;
-    if (p.debug & 8) {                     // diagnostics: m fastest (neighbours share the B panel)
-      tn = t / p.tiles_m;
-      tm = t - tn * p.tiles_m;
-    } else {
-      tm = t / p.tiles_n;
-      tn = t - tm * p.tiles_n;
-    }
-  };
-
-  auto issue = [&](int it) {
-    const int j = it / nk, kt = it - j * nk;
-    int tm, tn;
-    tile_coords(j, tm, tn);
-    const int k0 = k_begin + kt * BK;
-    const char* ab = (A_T == 0) ? p.A + ((long)tm * BM * p.lda + k0) * 2 : p.A + ((long)k0 * p.lda + (long)tm * BM) * 2;
-    const char* bb = (B_T == 0) ? p.B + ((long)tn * BN * p.ldb + k0) * 2 : p.B + ((long)k0 * p.ldb + (long)tn * BN) * 2;
-    char* st = smem + (it % NSTAGE) * STAGE + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < GA; ++i)
-      lds_dma16(ab + (long)offA[i] * 2, st + i * RND);
-#pragma unroll
-    for (int i = 0; i < GB; ++i)
-      lds_dma16(bb + (long)offB[i] * 2, st + A_BYTES + i * RND);
-  };
-
-  // ---- fragment read offsets
-  const int tq = l15 >> 2, tp = l15 & 3;
-  const int tr_f = (tq | ((lg & 1) << 2)) << 2;
-  int kc_off[KS];  // K-contiguous image: byte offset of (row l15 of a 16-row block, k-step s)
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-    kc_off[s] = (BK == 64) ? l15 * 128 + (((s * 4 + lg) ^ (l15 >> 1)) << 4) : l15 * 64 + ((lg ^ ((-(l15 >> 2)) & 3)) << 4);
-  auto read_frag = [&](const char* img, int trans, int rb_bytes, int base16, int s) -> bf16x8 {
-    if (!trans) {
-      return *(const bf16x8*)(img + base16 * (BK * 2) + kc_off[s]);
-    } else {
-      const char* pa = img + (s * 32 + lg * 8 + tq) * rb_bytes + ((((base16 >> 2) + tp) ^ tr_f) << 3);
-      bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)pa);
-      bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(pa + 4 * rb_bytes));
-      return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    }
-  };
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int pre = 0; pre < NSTAGE - 1; ++pre)
-    if (pre < total_it) issue(pre);
-
-  char* scr = smem + RING + wave * SCR;  // this wave's epilogue scratch: [16 rows][CW f32], 16-B chunks XOR row
-  int kt = 0, jt = 0;
-  for (int it = 0; it < total_it; ++it) {
-    if (it + NSTAGE - 2 < total_it) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * G) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (it + NSTAGE - 1 < total_it && !(p.debug & 1)) issue(it + NSTAGE - 1);
-
-    const char* As = smem + (it % NSTAGE) * STAGE;
-    const char* Bs = As + A_BYTES;
-    if (!(p.debug & 2))
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      bf16x8 af[WM], bf[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = read_frag(As, A_T, BM * 2, (wm * WM + i) * 16, s);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) bf[j] = read_frag(Bs, B_T, BN * 2, (wn * WN + j) * 16, s);
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-
-    if (++kt == nk) {
-      kt = 0;
-      int tm, tn;
-      tile_coords(jt, tm, tn);
-      ++jt;
-      tile_epilogue<WM, WN, CW, EPI>(acc, scr, p, tm * BM + wm * WM * 16, tn * BN + wn * WN * 16, split, lane);
-    }
-  }
-}
-
 // defined in gemm.hip / api.hip
 int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, int splits, float alpha, int accumulate,
                          hipStream_t st);
 void* ctx_workspace(vit_handle h, size_t* bytes);
-
-template <int BM, int BN, int BK, int NSTAGE, int NW, int AT, int BT, int EPI>
-static int launch_one(const Gemm2Args& a, dim3 grid, hipStream_t st) {
-  constexpr int smem = (NW == 8) ? 160 * 1024 : 80 * 1024;
-  static bool attr_done = false;
-  auto fn = gemm2_kernel<BM, BN, BK, NSTAGE, NW, AT, BT, EPI>;
-  if (!attr_done) {
-    VIT_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(fn, grid, dim3(NW * 64), smem, st, a);
-  VIT_LAUNCH_CHECK();
-  return VIT_OK;
-}
-
-// instantiated combinations: plain epilogue for all four layouts; GELU only for Y = X W^T; dGELU only for dX = dY W
-template <int BM, int BN, int BK, int NSTAGE, int NW>
-static int launch_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 grid, hipStream_t st) {
-  if (epi == 1) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 0, 1>(a, grid, st);
-  if (epi == 2) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 1, 2>(a, grid, st);
-  if (!at && !bt) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 0, 0>(a, grid, st);
-  if (!at && bt) return launch_one<BM, BN, BK, NSTAGE, NW, 0, 1, 0>(a, grid, st);
-  if (at && !bt) return launch_one<BM, BN, BK, NSTAGE, NW, 1, 0, 0>(a, grid, st);
-  return launch_one<BM, BN, BK, NSTAGE, NW, 1, 1, 0>(a, grid, st);
-}
 
 // Specialised epilogues of the ping-pong kernel (FAST): what the five hot GEMM kinds of a ViT layer need, with every
 // decision at compile time so that no load sits behind a runtime branch (hipcc waits vmcnt(0) after each such load,
@@ -1196,7 +1014,9 @@ unsigned long long* g_pp_stamps = nullptr;
 int g_pp_stamp_block = 0;
 #endif
 int g_gemm2_mode = -1;  // -1: read VIT_GEMM2 from the environment on first use
-int g_gemm2_debug = 0;
+#ifdef VIT_PP_DIAG
+int g_gemm2_debug = 0;  // diagnostic twin build only: vit_debug_pp_diag()
+#endif
 
 // returns 1 if handled (rc in *rc), 0 if the shape is not eligible
 int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* rc) {
@@ -1204,12 +1024,10 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     const char* e = getenv("VIT_GEMM2");
     g_gemm2_mode = e ? atoi(e) : 1;
   }
-  // 0 = off; 1 = automatic; 2 = 256x256 BK64 x2 stages; 3 = 256x128 BK64 x3 stages; 4 = 256x256 BK32 x4 stages;
-  // 5 = 256x256 BK64 ping-pong: wave halves one barrier out of phase (LOAD segment || MFMA segment), 8 half-tile ring;
-  // 6 = 256x128 BK32 x3 stages, 4 waves, TWO workgroups per CU
+  // 0 = off (generic 128x128 core only); 1 = automatic, 5 = the same choice named explicitly: the 256x256x64 ping-pong kernel
   const int mode = g_gemm2_mode;
   if (mode == 0) return 0;
-  if (d->M % 256 || d->N % 128 || d->K % 64) return 0;
+  if (d->M % 256 || d->N % 256 || d->K % 64) return 0;  // other shapes stay on the register-staged 128x128 core
   if (d->lda * 256 >= (1L << 30) || d->ldb * 256 >= (1L << 30)) return 0;  // int offsets inside a tile
   int epi = 0;
   if (d->act == VIT_ACT_GELU || d->act == VIT_ACT_GELU_GRAD) {
@@ -1219,17 +1037,9 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     if (d->a_trans || !d->b_trans) return 0;
     epi = 2;
   }
-  // automatic choice, from tools/gemm_bench.py on the ViT-B shapes (MI355X): the ping-pong kernel wins on every one of
-  // the twelve GEMMs of a layer (2.98 ms per layer against 3.41 ms for the best of the other cores); problems whose N
-  // is not a multiple of 256 stay on the register-staged 128x128 core.
-  int cfg = mode;
-  if (mode == 1) {
-    if (d->N % 256 == 0) cfg = 5;
-    else return 0;
-  }
-  if (d->N % 256 && cfg != 6) cfg = 3;
-  const int bn = (cfg == 3 || cfg == 6) ? 128 : 256;
-  const int slots = (cfg == 6) ? 512 : 256;
+  constexpr int cfg = 5;
+  const int bn = 256;
+  const int slots = ctx_num_cus(h);  // one workgroup per CU
 
   Gemm2Args a;
   a.A = (const char*)d->A; a.B = (const char*)d->B; a.C = (char*)d->C;
@@ -1275,7 +1085,9 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   a.act = d->act; a.c_dtype = d->c_dtype;
   a.drop = make_drop_h(h, d->dropout_p, d->seed, d->site);
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
+#ifdef VIT_PP_DIAG
   a.debug = g_gemm2_debug;
+#endif
 #ifdef VIT_PP_STAMP
   a.stamps = g_pp_stamps;
   a.stamp_block = g_pp_stamp_block;
@@ -1331,21 +1143,11 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     if (ws && wsb >= (size_t)a.tiles_m * 2 * d->N * sizeof(float)) a.colsum_part = (float*)ws;
   }
   {
-    static const int geo[7][5] = {{0}, {0}, {256, 256, 64, 2, 8}, {256, 128, 64, 3, 8}, {256, 256, 32, 4, 8}, {0}, {256, 128, 32, 3, 4}};
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
-    if (cfg == 5) snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, 8);
-    else snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm2_kernel<%d, %d, %d, %d, %d, %d, %d, %d>", geo[cfg][0], geo[cfg][1],
-                  geo[cfg][2], geo[cfg][3], geo[cfg][4], at, bt, epi);
+    snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, 8);
   }
-  int r;
-  if (cfg == 2) r = launch_cfg<256, 256, 64, 2, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else if (cfg == 3) r = launch_cfg<256, 128, 64, 3, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else if (cfg == 5) {
-    r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
-    if (r == VIT_OK && half_tail) r = launch_half_cfg(a, epi5, st);
-  }
-  else if (cfg == 6) r = launch_cfg<256, 128, 32, 3, 4>(a, d->a_trans, d->b_trans, epi, grid, st);
-  else r = launch_cfg<256, 256, 32, 4, 8>(a, d->a_trans, d->b_trans, epi, grid, st);
+  int r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
+  if (r == VIT_OK && half_tail) r = launch_half_cfg(a, epi5, st);
   if (r == VIT_OK && a.colsum_part) {
     r = launch_reduce_partials(a.colsum_part, a.tiles_m * 2, d->N, d->colsum_out, d->N, d->colsum_out, 0, st);
     g_colsum_fused = 1;

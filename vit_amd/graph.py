@@ -95,6 +95,7 @@ class GraphedTrainStep:
             eng.flat.copy_(keep[0]); optimizer._m.copy_(keep[1]); optimizer._v.copy_(keep[2])
             optimizer._step, eng.step_counter = keep[3], keep[4]
             self.state[5] = keep[3]
+            self._dev_step = keep[3]  # host mirror of the record's step counter
             if eng.shadow is not None:
                 vf.cast_f32_bf16(eng.flat, eng.shadow)
             eng.mark_shadow_fresh()
@@ -136,6 +137,12 @@ class GraphedTrainStep:
             self.labels.copy_(labels, non_blocking=True)
             self._src = (self._src[0], None, self._src[2], -1)
         self._set_lr(float(self.opt.param_groups[0]["lr"]))
+        if self._dev_step != int(self.opt._step):
+            # the record's step counter (AdamW bias corrections, dropout keys) is advanced by THIS graph's replays only: steps
+            # taken elsewhere in between -- another captured shape (an epoch's partial last batch), eager steps -- put it back
+            # in line with the optimizer's count before the replay reads it
+            self.state[5:6].fill_(int(self.opt._step))
+            self._dev_step = int(self.opt._step)
         # the bound record is only read by kernels of THIS graph; bind it around the replay so eager calls elsewhere (an
         # evaluation pass between steps) keep their host-seeded masks
         lib, h = self.h.lib, self.h.h
@@ -143,6 +150,7 @@ class GraphedTrainStep:
         self.graph.replay()
         _cabi.check(lib.vit_step_state_bind(h, None), "vit_step_state_bind")
         self.opt._step += 1          # host mirror of the device counter (no sync)
+        self._dev_step += 1
         self.eng.step_counter += 1
         self.eng.mark_shadow_fresh()
         return self.loss

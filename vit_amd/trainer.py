@@ -87,8 +87,9 @@ class Checkpointer:
         return v > self.best_score if self.mode == "max" else v < self.best_score
 
     def after_validation(self, trainer: "Trainer", module, logs: Dict[str, float]):
-        if hasattr(trainer.optimizer, "gather_sharded_state"):
-            trainer.optimizer.gather_sharded_state()  # 'zero1': a collective, so before the rank check
+        opt = getattr(trainer, "optimizer", None)
+        if hasattr(opt, "gather_sharded_state"):
+            opt.gather_sharded_state()  # 'zero1': a collective, so before the rank check
         if trainer.rank != 0:
             return
         os.makedirs(self.dirpath, exist_ok=True)
