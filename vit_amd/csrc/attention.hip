@@ -776,6 +776,26 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
   }
 }
 
+// Dropout keep FLAGS of 4 consecutive query rows at ONE key for the key-owner orientation of the backward kernels, from the
+// rows' keys `rk`.  The mask word belongs to a (row, key pair): lanes l15 and l15 ^ 1 hold the two keys of a pair; the even lane
+// evaluates rows 0, 1, the odd lane rows 2, 3, and they trade results across the lane pair by DPP (2 words + 2 moves per 4
+// elements).  Flags, not multipliers (r03): the draw of (row r, this lane's key) sits in the low or high half of the pair's word by
+// the key's parity (= the lane's); shifting the word left by 16 for even keys puts it in the high half either way, and
+// "draw >= thr" becomes ONE unsigned compare against thr << 16.  The caller selects with the flags and applies the kept
+// elements' 1 / (1 - p) where it is cheapest (an FMA operand, the dV accumulator at the end): 3 VALU per element less than
+// building {0, scale} multipliers.
+__device__ __forceinline__ void drop_keep4_keyowner(const DropCfg& d, const u32x4& rk, unsigned key, int l15, bool (&keep)[4]) {
+  const unsigned odd = (unsigned)l15 & 1u;
+  const unsigned ha = drop_bits(odd ? rk[2] : rk[0], key >> 1);
+  const unsigned hb = drop_bits(odd ? rk[3] : rk[1], key >> 1);
+  const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
+  const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
+  const unsigned h[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
+  const unsigned sh = odd ? 0u : 16u, thr16 = d.thr << 16;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) keep[r] = (h[r] << sh) >= thr16;
+}
+
 template <int DH, int RQ>
 __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
@@ -837,20 +857,31 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   const float c = p.scale * LOG2E;
   const unsigned half_cols = (unsigned)((T + 1) >> 1);
 
-  for (int kt = 0; kt < ntl; ++kt) {
+  // dropout row keys of this wave's rows; keep flags by compares against thr << 16 (high draw: the word itself, low draw: the
+  // word shifted up), the kept elements' 1 / (1 - p) as the FMA's multiplier (r03: 3 VALU per element less than multipliers)
+  unsigned rkey[RQ];
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq)
+    rkey[rq] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + (q00 + rq * 16 + l15)) : 0u;
+  const unsigned thr16 = p.drop.thr << 16;
+  const float dscale = p.drop.thr ? p.drop.scale : 1.0f;
+  // One 64-key tile; EDGE = the tile straddles T (per-key validity select).  Full tiles run the body without it (r03: the
+  // forward's peeling applied here -- ViT-L's T = 577 walks nine full tiles and one edge tile).
+  auto tile = [&](auto edgec, int kt) {
+    constexpr bool EDGE = decltype(edgec)::value;
     const int kb = kt * RT;
     const char* Kt = Kimg + kt * TILE;
     const char* Vt = Vimg + kt * TILE;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      if (kb + u * 32 >= T) continue;
+      if (EDGE && kb + u * 32 >= T) continue;
       f32x4 ds[RQ][2];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = 2 * u + jj;
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq) ds[rq][jj] = zero4();
-        if (kb + j * 16 < T) {
+        if (!EDGE || kb + j * 16 < T) {
           f32x4 s_[RQ], dp[RQ];
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
@@ -867,16 +898,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
           const unsigned key0 = kb + j * 16 + lg * 4;
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq) {
-            float k[4] = {1.f, 1.f, 1.f, 1.f};
+            bool keep[4] = {true, true, true, true};
             if (p.drop.thr) {
-              const unsigned long long drow = (unsigned long long)bh * T + (q00 + rq * 16 + l15);
-              drop_pair(p.drop, drow, half_cols, key0, k[0], k[1]);
-              drop_pair(p.drop, drow, half_cols, key0 + 2, k[2], k[3]);
+              const unsigned ha = drop_bits(rkey[rq], key0 >> 1), hb = drop_bits(rkey[rq], (key0 >> 1) + 1);
+              keep[0] = (ha << 16) >= thr16; keep[1] = ha >= thr16;
+              keep[2] = (hb << 16) >= thr16; keep[3] = hb >= thr16;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pr = ((int)key0 + r < T) ? fast_exp2(s_[rq][r] * c - lse2[rq]) : 0.f;
-              ds[rq][jj][r] = pr * (dp[rq][r] * k[r] - del[rq]);
+              float pr = fast_exp2(s_[rq][r] * c - lse2[rq]);
+              if (EDGE) pr = ((int)key0 + r < T) ? pr : 0.f;
+              ds[rq][jj][r] = pr * fmaf(keep[r] ? dp[rq][r] : 0.f, dscale, -del[rq]);
             }
           }
         }
@@ -886,12 +918,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
       for (int rq = 0; rq < RQ; ++rq) df[rq] = pack8(ds[rq][0], ds[rq][1]);
 #pragma unroll
       for (int dt = 0; dt < DH / 16; ++dt) {
-        const bf16x8 ktf = frag_cols<DH>(Kt, u * 32, (kb + u * 32 + 16 < T) ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
+        const bf16x8 ktf = frag_cols<DH>(Kt, u * 32, (!EDGE || kb + u * 32 + 16 < T) ? u * 32 + 16 : u * 32, dt * 16, l15, lg);
 #pragma unroll
         for (int rq = 0; rq < RQ; ++rq)
           dqt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, df[rq], dqt[rq][dt], 0, 0, 0);
       }
     }
+  };
+  {
+    using std::integral_constant;
+    const int nfull = T / RT;
+    for (int kt = 0; kt < nfull; ++kt) tile(integral_constant<bool, false>{}, kt);
+    if (nfull * RT < T) tile(integral_constant<bool, true>{}, nfull);
   }
   f32x4 cs[DH / 16];
 #pragma unroll
@@ -972,6 +1010,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
     for (int i = 0; i < DH / 16; ++i) dkt[rq][i] = dvt[rq][i] = zero4();
   }
   const float c = p.scale * LOG2E;
+  const float dscale = p.drop.thr ? p.drop.scale : 1.0f;
 
   for (int qt = 0; qt < ntl; ++qt) {
     const int qb0 = qt * RT;
@@ -1007,17 +1046,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
           for (int rq = 0; rq < RQ; ++rq) {
             const unsigned key = k00 + rq * 16 + l15;
             float pdv[4], dsv[4];
+            bool keep[4] = {true, true, true, true};
+            // the lane pair (l15, l15 ^ 1) holds the two keys of a mask word: two hashes per four elements, traded by DPP, and
+            // compare-only flags (key tiles start at even keys: key parity == lane parity)
+            if (p.drop.thr) drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
-              float mk = 1.f;
-              if (p.drop.thr) {
-                const unsigned hsh = drop_bits(rk4[r], key >> 1);
-                const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
-                mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
-              }
-              pdv[r] = pr * mk;
-              dsv[r] = pr * (dp[rq][r] * mk - d4[r]);
+              pdv[r] = keep[r] ? pr : 0.f;  // 1 / (1 - p) goes onto dV once, at the end
+              dsv[r] = pr * fmaf(keep[r] ? dp[rq][r] : 0.f, dscale, -d4[r]);
             }
             pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
             dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
@@ -1056,7 +1093,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
       for (int dt = 0; dt < DH / 16; ++dt) {
         const int d = dt * 16 + lg * 4;
         if (d < dh) {
-          const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
+          const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt] * dscale;
           u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
           u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
           *(u32x2*)(ok + d) = pk;
@@ -1806,6 +1843,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   const int G = nheads * np;  // pairs this workgroup walks
   const float c = p.scale * LOG2E;
   const bool has_lo = p.ctx_lo != nullptr;
+  const float dscale = p.drop.thr ? p.drop.scale : 1.0f;  // 1 / (1 - p) of the kept probabilities
   // roles: waves 0-3 load dO / O / O_lo / lse of 8 rows each and derive their statistics (D); waves 4-7 load Q and run the
   // dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
   const bool is_d = wave < 4, is_b = wave >= 4;
@@ -1980,7 +2018,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
             u32x2 pk[2], pv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const f32x4 a = dkt[rq][dp * 2 + i] * p.scale, v = dvt[rq][dp * 2 + i];
+              const f32x4 a = dkt[rq][dp * 2 + i] * p.scale, v = dvt[rq][dp * 2 + i] * dscale;
               pk[i] = (u32x2){pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
               pv[i] = (u32x2){pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
               if (okk) {
@@ -2079,14 +2117,15 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
             for (int rq = 0; rq < RQ; ++rq) {
               if (rq == 1 && !own1) continue;
               const unsigned key = (rq ? kt1 : kt0) * 16 + l15;
-              float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-              if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
+              float pdv[4], dsv[4];
+              bool keep[4] = {true, true, true, true};
+              if (p.drop.thr) drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
                 const float pr = fast_exp2(s_[rq][r] * c - (l4[r] + kinf[rq]));
-                pdv[r] = pr * mk[r];
-                dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
+                pdv[r] = keep[r] ? pr : 0.f;  // the kept elements' 1 / (1 - p) is applied to dV once, when the head ends
+                dsv[r] = pr * fmaf(keep[r] ? dp[rq][r] : 0.f, dscale, -d4[r]);
               }
               pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
               dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
