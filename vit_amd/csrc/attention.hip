@@ -786,11 +786,17 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
 // building {0, scale} multipliers.
 __device__ __forceinline__ void drop_keep4_keyowner(const DropCfg& d, const u32x4& rk, unsigned key, int l15, bool (&keep)[4]) {
   const unsigned odd = (unsigned)l15 & 1u;
-  const unsigned ha = drop_bits(odd ? rk[2] : rk[0], key >> 1);
-  const unsigned hb = drop_bits(odd ? rk[3] : rk[1], key >> 1);
-  const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
-  const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
-  const unsigned h[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
+  // dropout off: thr << 16 = 0 and every compare below is true -- the flags are formed OUTSIDE the uniform branch, so they are
+  // plain compare results (inside it the compiler merged them with the "off" default through a dozen scalar mask instructions
+  // per tile: ISA of the A stage, 90 of 586 instructions)
+  unsigned h[4] = {~0u, ~0u, ~0u, ~0u};
+  if (d.thr) {
+    const unsigned ha = drop_bits(odd ? rk[2] : rk[0], key >> 1);
+    const unsigned hb = drop_bits(odd ? rk[3] : rk[1], key >> 1);
+    const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
+    const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
+    h[0] = odd ? oa : ha; h[1] = odd ? ob : hb; h[2] = odd ? ha : oa; h[3] = odd ? hb : ob;
+  }
   const unsigned sh = odd ? 0u : 16u, thr16 = d.thr << 16;
 #pragma unroll
   for (int r = 0; r < 4; ++r) keep[r] = (h[r] << sh) >= thr16;
@@ -898,12 +904,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
           const unsigned key0 = kb + j * 16 + lg * 4;
 #pragma unroll
           for (int rq = 0; rq < RQ; ++rq) {
-            bool keep[4] = {true, true, true, true};
+            unsigned ha = ~0u, hb = ~0u;  // dropout off: thr16 = 0, every compare true
             if (p.drop.thr) {
-              const unsigned ha = drop_bits(rkey[rq], key0 >> 1), hb = drop_bits(rkey[rq], (key0 >> 1) + 1);
-              keep[0] = (ha << 16) >= thr16; keep[1] = ha >= thr16;
-              keep[2] = (hb << 16) >= thr16; keep[3] = hb >= thr16;
+              ha = drop_bits(rkey[rq], key0 >> 1);
+              hb = drop_bits(rkey[rq], (key0 >> 1) + 1);
             }
+            const bool keep[4] = {(ha << 16) >= thr16, ha >= thr16, (hb << 16) >= thr16, hb >= thr16};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float pr = fast_exp2(s_[rq][r] * c - lse2[rq]);
@@ -1046,10 +1052,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
           for (int rq = 0; rq < RQ; ++rq) {
             const unsigned key = k00 + rq * 16 + l15;
             float pdv[4], dsv[4];
-            bool keep[4] = {true, true, true, true};
+            bool keep[4];
             // the lane pair (l15, l15 ^ 1) holds the two keys of a mask word: two hashes per four elements, traded by DPP, and
             // compare-only flags (key tiles start at even keys: key parity == lane parity)
-            if (p.drop.thr) drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
+            drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
@@ -2118,8 +2124,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
               if (rq == 1 && !own1) continue;
               const unsigned key = (rq ? kt1 : kt0) * 16 + l15;
               float pdv[4], dsv[4];
-              bool keep[4] = {true, true, true, true};
-              if (p.drop.thr) drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
+              bool keep[4];
+              drop_keep4_keyowner(p.drop, rk4, key, l15, keep);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
