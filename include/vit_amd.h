@@ -55,6 +55,8 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "attn_bwd_fused": attention backward form: 4 (default) = the pair-pipelined single kernel where it fits (head_dim 64,
  *                64 <= T <= 208), else as 3; 3 = the persistent single kernel (head_dim 64, T <= 224), else as 1; 1 / 2 = the
  *                fused single kernel with 8 / 16 waves (T <= 240); 0 = the dQ + dK/dV pair.
+ *   "attn32_mfma": 1 (default) = fp32 attention (precision '32') at head_dim 64 runs on the f32-input matrix instructions
+ *                (v_mfma_f32_16x16x4_f32: exact f32 products and accumulation); 0 = the one-wave-per-row vector kernels.
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.
  *   "attn_res_max_t": longest sequence the resident attention kernels take (default 592 = what fits the LDS at head_dim
  *                64); longer ones, or everything with 0, go to the tiled kernels.

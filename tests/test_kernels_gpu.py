@@ -526,7 +526,8 @@ def test_gemm_x3_epilogues(dev):
     assert rel(dw, (dy.double().t() @ x.double()).float()) < 3e-5
 
 
-@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 5, 64), (1, 2, 197, 64), (1, 1, 70, 128)])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 5, 64), (1, 2, 197, 64), (1, 1, 70, 128), (2, 2, 130, 64),
+                                      (1, 2, 577, 64), (3, 1, 64, 64)])  # head_dim 64: the f32-MFMA kernels; others: one wave per row
 def test_attention_f32(dev, B, H, T, dh):
     import vit_amd.functional as vf
 

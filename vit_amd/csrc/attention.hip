@@ -2431,9 +2431,311 @@ __global__ __launch_bounds__(256) void attn32_dkv_kernel(Attn32Args p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 attention on MFMA (r03)
+// The one-wave-per-row kernels above are exact but slow: 258 of the 368 ms of a ViT-B step in precision '32' (r03 profile).
+// gfx950 has f32-input matrix instructions (v_mfma_f32_16x16x4_f32: exact f32 products and f32 accumulation, bit for bit
+// a k-ordered fmaf chain, at the f32 vector rate per instruction but 64 lanes x 16 results each), so the same flash-style
+// tiling as the bf16 kernels runs on them: 4 waves x 16 rows, 64-row K / V (or Q / dO) tiles of f32 in the LDS, the swapped
+// orientation that keeps the softmax statistics lane-local, and the accumulator tile of one product being the B operand of
+// the next (a lane's register r IS the k-slot (lane >> 4) of MFMA step r: no lane movement).  head_dim 64 only (ViT-B / -L);
+// other head sizes and the attention-map output stay on the kernels above.
+// Operand maps of v_mfma_f32_16x16x4_f32: A[row = l & 15][k = l >> 4], B[k = l >> 4][col = l & 15] (one float per lane each),
+// C / D as for every 16x16 MFMA.  The contraction over d (64) takes 16 steps; step s uses d = 16 g + s for lane group g, so a
+// lane's 16 operand values are 64 CONTIGUOUS bytes of its row (4 x ds_read_b128).
+// LDS tile [64 rows][64 f32]: row r at r * 256, 16-byte chunk c at ((c ^ sw(r)) << 4), sw(r) = (r & 3) | ((r & 8) ? 12 : 0):
+// the row reads (a 16-lane group = 8 rows at chunk i of one lane group and 8 rows at chunk i + 4 of the next) tile the
+// 256-byte bank row; the per-element reads of the third product are 2-way at worst, one per 32-cycle MFMA.
+__device__ __forceinline__ int t32_off(int r, int c) { return r * 256 + ((c ^ ((r & 3) | ((r & 8) ? 12 : 0))) << 4); }
+__device__ __forceinline__ void load_tile32(char* img, const float* g, long ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i, r = q >> 4, c = q & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + r < nrows) v = *(const f32x4*)(g + (long)(row0 + r) * ld + c * 4);
+    *(f32x4*)(img + t32_off(r, c)) = v;
+  }
+}
+// the 16 operand values of row (rb + l15) for the 16 contraction steps: d = 16 g + s
+__device__ __forceinline__ void frag32_rows(float (&f)[16], const char* img, int rb, int l15, int lg) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = *(const f32x4*)(img + t32_off(rb + l15, 4 * lg + i));
+    f[4 * i] = v[0]; f[4 * i + 1] = v[1]; f[4 * i + 2] = v[2]; f[4 * i + 3] = v[3];
+  }
+}
+__device__ __forceinline__ void load_own32(float (&f)[16], const float* g, long ld, int row, int nrows, int lg) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nrows) v = *(const f32x4*)(g + (long)row * ld + 16 * lg + 4 * i);
+    f[4 * i] = v[0]; f[4 * i + 1] = v[1]; f[4 * i + 2] = v[2]; f[4 * i + 3] = v[3];
+  }
+}
+__device__ __forceinline__ float t32_elem(const char* img, int r, int col) {
+  return *(const float*)(img + t32_off(r, col >> 2) + (col & 3) * 4);
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256) void attn32m_fwd_kernel(Attn32Args p) {
+  resolve_drop(p.drop);
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 256];
+  char* Kimg = smem;
+  char* Vimg = smem + 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T;
+  const long ld = 3L * p.H * 64, ldc = (long)p.H * 64;
+  const float* qb = p.qkv + (long)b * T * ld + h * 64;
+  const float* kb_ = qb + p.H * 64;
+  const float* vb = kb_ + p.H * 64;
+  const int q0 = (blockIdx.x * 4 + wave) * 16, q = q0 + l15;
+  float qf[16];
+  load_own32(qf, qb, ld, q, T, lg);
+  const float c = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.f;
+  f32x4 ot[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ot[i] = zero4();
+  const unsigned long long drow = (unsigned long long)bh * T + q;
+  for (int kb = 0; kb < T; kb += 64) {
+    if (kb) __syncthreads();
+    load_tile32(Kimg, kb_, ld, kb, T, tid);
+    load_tile32(Vimg, vb, ld, kb, T, tid);
+    __syncthreads();
+    f32x4 st[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j * 16 < T) {
+        float kf[16];
+        frag32_rows(kf, Kimg, j * 16, l15, lg);
+        f32x4 a = zero4();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a = MFMA32(kf[s], qf[s], a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = (kb + j * 16 + lg * 4 + r < T) ? a[r] * c : -INFINITY;
+          mx = fmaxf(mx, a[r]);
+        }
+        st[j] = a;
+      } else {
+        st[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+    mx = grp4_max(mx);
+    const float mn = fmaxf(m, mx);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st[j][r] = exp2f(st[j][r] - mn);
+        ls += st[j][r];
+      }
+    l = l * alpha + ls;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ot[i] *= alpha;
+    if (p.drop.thr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned key = kb + j * 16 + lg * 4;
+        float k0, k1, k2, k3;
+        drop_pair(p.drop, drow, 0u, key, k0, k1);
+        drop_pair(p.drop, drow, 0u, key + 2, k2, k3);
+        st[j][0] *= k0; st[j][1] *= k1; st[j][2] *= k2; st[j][3] *= k3;
+      }
+    }
+    // O^T[d][q] += sum over keys V^T[d][key] P^T[key][q]: MFMA step (j, r) has k-slot g = key 16 j + 4 g + r, whose
+    // probability is this lane's register st[j][r]; the A operand is V[that key][dt * 16 + l15]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j * 16 < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kr = j * 16 + lg * 4 + r;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) ot[dt] = MFMA32(t32_elem(Vimg, kr, dt * 16 + l15), st[j][r], ot[dt]);
+        }
+      }
+    }
+  }
+  l = grp4_sum(l);
+  if (q < T) {
+    const float inv = 1.0f / l;
+    float* o = p.ctx + ((long)b * T + q) * ldc + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(o + dt * 16 + lg * 4) = ot[dt] * inv;
+    if (lg == 0 && p.lse) p.lse[(long)bh * T + q] = (m + log2f(l)) * LN2;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn32m_dq_kernel(Attn32Args p) {
+  resolve_drop(p.drop);
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 256];
+  char* Kimg = smem;
+  char* Vimg = smem + 64 * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T;
+  const long ld = 3L * p.H * 64, ldc = (long)p.H * 64;
+  const float* qb = p.qkv + (long)b * T * ld + h * 64;
+  const float* kb_ = qb + p.H * 64;
+  const float* vb = kb_ + p.H * 64;
+  const float* dob = p.dctx + (long)b * T * ldc + h * 64;
+  const float* ob = p.ctx + (long)b * T * ldc + h * 64;
+  const int q0 = (blockIdx.x * 4 + wave) * 16, q = q0 + l15;
+  float qf[16], dof[16];
+  load_own32(qf, qb, ld, q, T, lg);
+  load_own32(dof, dob, ldc, q, T, lg);
+  const float c = p.scale * LOG2E;
+  const float lse2 = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
+  float del = 0.f;  // delta[q] = rowsum(dO o O): this lane's 16 columns, then the 4 lane groups
+  {
+    float of[16];
+    load_own32(of, ob, ldc, q, T, lg);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) del = fmaf(of[s], dof[s], del);
+    del = grp4_sum(del);
+    if (q < T && lg == 0) p.delta[(long)bh * T + q] = del;
+  }
+  f32x4 dqt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dqt[i] = zero4();
+  const unsigned long long drow = (unsigned long long)bh * T + q;
+  for (int kb = 0; kb < T; kb += 64) {
+    if (kb) __syncthreads();
+    load_tile32(Kimg, kb_, ld, kb, T, tid);
+    load_tile32(Vimg, vb, ld, kb, T, tid);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (kb + j * 16 >= T) continue;
+      float kf[16], vf[16];
+      frag32_rows(kf, Kimg, j * 16, l15, lg);
+      frag32_rows(vf, Vimg, j * 16, l15, lg);
+      f32x4 s_ = zero4(), dp = zero4();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        s_ = MFMA32(kf[s], qf[s], s_);
+        dp = MFMA32(vf[s], dof[s], dp);
+      }
+      const unsigned key0 = kb + j * 16 + lg * 4;
+      float k[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.drop.thr) {
+        drop_pair(p.drop, drow, 0u, key0, k[0], k[1]);
+        drop_pair(p.drop, drow, 0u, key0 + 2, k[2], k[3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = ((int)key0 + r < T) ? exp2f(s_[r] * c - lse2) : 0.f;
+        const float ds = pr * (dp[r] * k[r] - del);
+        const int kr = j * 16 + lg * 4 + r;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqt[dt] = MFMA32(t32_elem(Kimg, kr, dt * 16 + l15), ds, dqt[dt]);
+      }
+    }
+  }
+  if (q < T) {
+    float* o = p.dqkv + ((long)b * T + q) * ld + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *(f32x4*)(o + dt * 16 + lg * 4) = dqt[dt] * p.scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void attn32m_dkv_kernel(Attn32Args p) {
+  resolve_drop(p.drop);
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 256 + 2 * 64 * 4];
+  char* Qimg = smem;
+  char* Oimg = smem + 64 * 256;
+  float* lse_s = (float*)(smem + 2 * 64 * 256);
+  float* del_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T;
+  const long ld = 3L * p.H * 64, ldc = (long)p.H * 64;
+  const float* qb = p.qkv + (long)b * T * ld + h * 64;
+  const float* kb_ = qb + p.H * 64;
+  const float* vb = kb_ + p.H * 64;
+  const float* dob = p.dctx + (long)b * T * ldc + h * 64;
+  const int key = (blockIdx.x * 4 + wave) * 16 + l15;
+  float kf[16], vf[16];
+  load_own32(kf, kb_, ld, key, T, lg);
+  load_own32(vf, vb, ld, key, T, lg);
+  const float c = p.scale * LOG2E;
+  f32x4 dkt[4], dvt[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dkt[i] = dvt[i] = zero4();
+  for (int qb0 = 0; qb0 < T; qb0 += 64) {
+    if (qb0) __syncthreads();
+    load_tile32(Qimg, qb, ld, qb0, T, tid);
+    load_tile32(Oimg, dob, ldc, qb0, T, tid);
+    if (tid < 64) {
+      const int qq = qb0 + tid;
+      lse_s[tid] = qq < T ? p.lse[(long)bh * T + qq] * LOG2E : INFINITY;
+      del_s[tid] = qq < T ? p.delta[(long)bh * T + qq] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (qb0 + j * 16 >= T) continue;
+      float qfr[16], ofr[16];
+      frag32_rows(qfr, Qimg, j * 16, l15, lg);
+      frag32_rows(ofr, Oimg, j * 16, l15, lg);
+      f32x4 s_ = zero4(), dp = zero4();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        s_ = MFMA32(qfr[s], kf[s], s_);
+        dp = MFMA32(ofr[s], vf[s], dp);
+      }
+      const f32x4 l4 = *(const f32x4*)(lse_s + j * 16 + lg * 4);
+      const f32x4 d4 = *(const f32x4*)(del_s + j * 16 + lg * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = exp2f(s_[r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
+        float mk = 1.f;
+        if (p.drop.thr) {
+          const unsigned long long row = (unsigned long long)bh * T + (qb0 + j * 16 + lg * 4 + r);
+          const unsigned hsh = drop_bits(drop_rowkey(p.drop, row), (unsigned)key >> 1);
+          const unsigned r16 = (key & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+          mk = r16 >= p.drop.thr ? p.drop.scale : 0.f;
+        }
+        const float pd = pr * mk, ds = pr * (dp[r] * mk - d4[r]);
+        const int qr = j * 16 + lg * 4 + r;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dvt[dt] = MFMA32(t32_elem(Oimg, qr, dt * 16 + l15), pd, dvt[dt]);
+          dkt[dt] = MFMA32(t32_elem(Qimg, qr, dt * 16 + l15), ds, dkt[dt]);
+        }
+      }
+    }
+  }
+  if (key < T) {
+    float* ok = p.dqkv + ((long)b * T + key) * ld + p.H * 64 + h * 64;
+    float* ov = ok + p.H * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *(f32x4*)(ok + dt * 16 + lg * 4) = dkt[dt] * p.scale;
+      *(f32x4*)(ov + dt * 16 + lg * 4) = dvt[dt];
+    }
+  }
+}
+#undef MFMA32
+
+int g_attn32_mfma = 1;  // vit_set_option("attn32_mfma"): 0 = the one-wave-per-row fp32 kernels for every shape
+
 static int launch_attn32(int which, Attn32Args& a, hipStream_t st) {
   VIT_CHECK(a.T <= 4096 && a.dh <= 128 && (a.dh % 4) == 0, VIT_ERR_UNSUPPORTED,
             "fp32 attention supports T <= 4096 and dh <= 128 (multiple of 4); got T=%d dh=%d", a.T, a.dh);
+  if (g_attn32_mfma && a.dh == 64 && !a.probs) {  // head_dim 64, no attention-map output: the f32-MFMA kernels
+    dim3 grid(cdiv(cdiv(a.T, 16), 4), a.B * a.H);
+    if (which == 0) hipLaunchKernelGGL(attn32m_fwd_kernel, grid, dim3(256), 0, st, a);
+    else if (which == 1) hipLaunchKernelGGL(attn32m_dq_kernel, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn32m_dkv_kernel, grid, dim3(256), 0, st, a);
+    VIT_LAUNCH_CHECK();
+    return VIT_OK;
+  }
   a.Tp = (a.T + 63) & ~63;
   const size_t smem = (size_t)4 * (2 * a.Tp + 256) * sizeof(float);
   const long rows = (long)a.B * a.H * a.T;

@@ -246,17 +246,18 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
 #endif
         if (p.act == VIT_ACT_GELU_GRAD) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            float g_, d_;
-            gelu_both(o[r], g_, d_);
-            o[r] = g_;
-            sv[r] = d_;
+          for (int r = 0; r < 8; r += 2) {
+            f32x2 g_, d_;
+            gelu_both2((f32x2){o[r], o[r + 1]}, g_, d_);
+            o[r] = g_[0]; o[r + 1] = g_[1];
+            sv[r] = d_[0]; sv[r + 1] = d_[1];
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            sv[r] = o[r];
-            o[r] = gelu_erf(o[r]);
+          for (int r = 0; r < 8; r += 2) {
+            sv[r] = o[r]; sv[r + 1] = o[r + 1];
+            const f32x2 g_ = gelu_erf2((f32x2){o[r], o[r + 1]});
+            o[r] = g_[0]; o[r + 1] = g_[1];
           }
         }
 #ifdef VIT_EPI_NOAUX  // timing experiment: the second output is not stored
