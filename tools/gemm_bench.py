@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--cores", default="0,5")
     ap.add_argument("--M", type=int, default=50432)
+    ap.add_argument("--only", default="", help="substring filter on the case names, e.g. 'fc1' or 'dX  fc2'")
     args = ap.parse_args()
     cores = [c for c in args.cores.split(",")]  # "5" or "5s8" / "5s10": ping-pong core with an 8- / 10-slot ring
     def select(c):  # "5", "5s10" (10-slot ring), "5b0" (always 256 workgroups), "5h0" (no half-tile tail launch)
@@ -58,6 +59,8 @@ def main():
         "dW  out   [M,768]^T x [M,768]": (lambda: vf.gemm(x768, x768, M=D, N=D, K=M, a_trans=True, b_trans=True, out=dWo, split_k=-1), 2 * M * D * D),
         "dW  qkv   [M,2304]^T x [M,768]": (lambda: vf.gemm(x2304, x768, M=3 * D, N=D, K=M, a_trans=True, b_trans=True, out=dWqkv, split_k=-1), 2 * M * 3 * D * D),
     }
+    if args.only:
+        cases = {k: v for k, v in cases.items() if any(o in k for o in args.only.split(","))}
     times = {k: {c: [] for c in cores} for k in cases}
     for r in range(args.rounds + 1):
         for name, (fn, fl) in cases.items():

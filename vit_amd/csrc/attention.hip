@@ -1839,6 +1839,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   const long ld = 3L * p.H * DH, ldc = (long)p.H * DH, HD = (long)p.H * DH;
   const int R = (T + 15) & ~15, nq = R >> 4, np = (nq + 1) >> 1, nks = (T + 31) >> 5;
   char* ring = smem;
+  const unsigned ring_a = lds_addr_of(smem);   // DMA destinations are raw LDS addresses
   char* lse_raw = ring + PIPE_NS * PIPE_SLOT;  // [slot][row group][64 words]: raw lse, word l = lse of row (l >> 3) of the group
   char* Kimg0 = lse_raw + PIPE_NS * 4 * 256;   // two K images (heads alternate)
   char* Vimg = Kimg0 + 2 * R * 128;
@@ -1876,32 +1877,34 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   auto qoff_of = [&](const PipeHead& h) -> long { return (long)h.b * T * ld + (long)h.hh * DH; };
   auto coff_of = [&](const PipeHead& h) -> long { return (long)h.b * T * ldc + (long)h.hh * DH; };
 
-  // ---- L: the rows of pair pp of head h into ring slot s; returns the number of pieces this wave issued
-  auto issue_L = [&](const PipeHead& h, int pp, int s) -> int {
-    // waves 0-3 issue every piece of their 8 rows (Q too): the address set-up of an issue costs ~1 000 cycles per wave however
-    // few pieces follow (stamps), and waves 4-7 carry the dQ stage -- they issue nothing
-    char* slot = ring + s * PIPE_SLOT;
-    const int row = min(pp * 32 + grp * 8 + rl8, T - 1);
+  // byte offsets of the LDS regions (integers: DMA destinations are raw LDS addresses, see lds_dma16_s)
+  const int off_lse = PIPE_NS * PIPE_SLOT, off_K = off_lse + PIPE_NS * 4 * 256, off_V = off_K + 2 * R * 128;
+  auto issue_L = [&](int bh, long qo, long co, int pp, int s) -> int {
+    // waves 0-3 issue every piece of their 8 rows (Q too), waves 4-7 carry the dQ stage -- they issue nothing.  Uniform 64-bit
+    // bases (qo, co: element offsets of the head, computed once per head) + 32-bit lane offsets (bytes inside the head's rows:
+    // < 208 rows x 3 D x 2 B): the first form spent ~180 cycles per piece, most of it 64-bit address arithmetic (stamps)
     if (is_b) return 0;
-    lds_dma16(p.qkv + qoff_of(h) + (long)row * ld + csw8, slot + grp * 1024);
-    const long ro = coff_of(h) + (long)row * ldc;
-    lds_dma16(p.dctx + ro + csw8, slot + 4096 + grp * 1024);
-    lds_dma16(p.ctx + ro + clin8, slot + 8192 + grp * 1024);
-    if (has_lo) lds_dma16(p.ctx_lo + ro + clin8, slot + 12288 + grp * 1024);
-    lds_dma4(p.lse + (long)h.bh * T + row, lse_raw + (s * 4 + grp) * 256);
+    const unsigned slot = ring_a + s * PIPE_SLOT + grp * 1024;
+    const unsigned row = (unsigned)min(pp * 32 + grp * 8 + rl8, T - 1);
+    const unsigned oq = __umul24(row, (unsigned)(ld * 2)) + (unsigned)csw8 * 2, oc = __umul24(row, (unsigned)(ldc * 2));
+    lds_dma16_s(p.qkv + qo, oq, slot);
+    lds_dma16_s(p.dctx + co, oc + (unsigned)csw8 * 2, slot + 4096);
+    lds_dma16_s(p.ctx + co, oc + (unsigned)clin8 * 2, slot + 8192);
+    if (has_lo) lds_dma16_s(p.ctx_lo + co, oc + (unsigned)clin8 * 2, slot + 12288);
+    lds_dma4_s(p.lse + (long)bh * T, row * 4u, ring_a + off_lse + (s * 4 + grp) * 256);
     return has_lo ? 5 : 4;
   };
   // ---- KV: pieces [j0, j0 + n) of a head's K image (buffer kbuf) and V image; piece j < R/8: K rows 8j.., else V
-  auto issue_KV = [&](const PipeHead& h, int kbuf, int j0, int n) -> int {
+  auto issue_KV = [&](long qo, int kbuf, int j0, int n) -> int {
     const int nk = R >> 3;
-    const short* kb_ = p.qkv + qoff_of(h) + HD;
-    char* Kd = Kimg0 + kbuf * (R * 128);
+    const short* kb_ = p.qkv + qo + HD;
+    const unsigned Kd = ring_a + off_K + kbuf * (R * 128), Vd = ring_a + off_V;
     int cnt = 0;
     for (int j = j0; j < j0 + n && j < 2 * nk; ++j) {
       const bool isk = j < nk;
       const int jj = isk ? j : j - nk;
-      const int row = min(jj * 8 + rl8, T - 1);
-      lds_dma16((isk ? kb_ : kb_ + HD) + (long)row * ld + csw8, (isk ? Kd : Vimg) + jj * 1024);
+      const unsigned row = (unsigned)min(jj * 8 + rl8, T - 1);
+      lds_dma16_s(isk ? kb_ : kb_ + HD, __umul24(row, (unsigned)(ld * 2)) + (unsigned)csw8 * 2, (isk ? Kd : Vd) + jj * 1024);
       ++cnt;
     }
     return cnt;
@@ -1922,6 +1925,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   // (head ordinal, pair) of g - 1, g, g + 1, g + 2; g runs from -2
   int hm = 0, pm = -3, h0 = 0, p0 = -2, h1 = 0, p1 = -1, h2 = 0, p2 = 0;
   PipeHead Hm = head_of(0), H0 = Hm, H1 = Hm, H2 = Hm, Hn = Hm;
+  long q2 = qoff_of(H2), c2 = coff_of(H2), qn = q2;  // element offsets of heads H2 / Hn: 64-bit products, once per head
 #ifdef VIT_PIPE_PRIO  // experiment: the second-dispatched half (waves 4-7) loses issue arbitration to the older half
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -1984,16 +1988,15 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
             dq0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a, f.ds, dq0, 0, 0, 0);
             dq1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.b, f.ds, dq1, 0, 0, 0);
           };
-          {  // two steps of fragments in flight (24 VGPRs): deeper prefetch spilled the A stage's registers to scratch
-            BFrag fa = bload(0), fb = bload(1);
+          {  // BD steps of fragments in flight (12 VGPRs each); 3 and 4 measured the same as 2 (r03: 307 us each)
+            constexpr int BD = 2;
+            BFrag f[BD];
+#pragma unroll
+            for (int i = 0; i < BD; ++i) f[i] = bload(i);
 #pragma unroll
             for (int ks = 0; ks < 7; ++ks) {
-              const BFrag cur = (ks & 1) ? fb : fa;
-              bmma(cur);
-              if (ks + 2 < 7) {
-                if (ks & 1) fb = bload(ks + 2);
-                else fa = bload(ks + 2);
-              }
+              bmma(f[ks % BD]);
+              if (ks + BD < 7) f[ks % BD] = bload(ks + BD);
             }
           }
           const int q = qt * 16 + l15o;
@@ -2068,12 +2071,15 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     int nissued = 0;
     if (g == -2) {  // prologue: the first head's images, spread over the waves
       const int per = (kv_total + 7) >> 3;
-      nissued += issue_KV(H2, 0, wave * per, per);
+      nissued += issue_KV(q2, 0, wave * per, per);
     } else if (is_d && v0 && p0 >= 1 && h0 + 1 < nheads) {
-      if (p0 == 1) Hn = head_of(h0 + 1);
-      nissued += issue_KV(Hn, (h0 + 1) & 1, ((p0 - 1) * 4 + wave) * kvp, kvp);
+      if (p0 == 1) {
+        Hn = head_of(h0 + 1);
+        qn = qoff_of(Hn);
+      }
+      nissued += issue_KV(qn, (h0 + 1) & 1, ((p0 - 1) * 4 + wave) * kvp, kvp);
     }
-    if (v2 && !(VIT_PIPE_SKIP & 4)) nissued += issue_L(H2, p2, (g + 2) % PIPE_NS);
+    if (v2 && !(VIT_PIPE_SKIP & 4)) nissued += issue_L(H2.bh, q2, c2, p2, (g + 2) % PIPE_NS);
     PIPE_ST(1)  // DMA issue
     // ------------------------------------------------------------------ A(g)
     if (v0) {
@@ -2195,7 +2201,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     if (++p2 == np) {
       p2 = 0;
       ++h2;
-      if (h2 < nheads) H2 = head_of(h2);
+      if (h2 < nheads) {
+        H2 = head_of(h2);
+        q2 = qoff_of(H2);
+        c2 = coff_of(H2);
+      }
     }
   }
 #ifdef VIT_PIPE_STAMP

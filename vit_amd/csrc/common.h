@@ -226,6 +226,20 @@ __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst /* wave
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(a) : "memory");
 }
 #endif
+// The same two with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: the lane address is one
+// 32-bit multiply-add instead of a 64-bit one per piece (the attention backward's DMA issue was ~180 cycles per piece, most of
+// it address arithmetic: stamps).  base + off is the byte address; off < 2^32.
+// lds_addr: the destination as a raw LDS byte address (lds_addr_of), wave-uniform -- a generic `char*` costs a null check and
+// an aperture compare per piece when the compiler cannot see the address space through a select.
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void lds_dma16_s(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_addr /* wave-uniform */) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory");
+}
+__device__ __forceinline__ void lds_dma4_s(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_addr /* wave-uniform */) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory");
+}
 
 // the handle's bound per-step state (api.hip): [key0, key1, lr, bc1, rsqrt_bc2, step] in device memory, or NULL
 struct StepState { unsigned key0, key1; float lr, bc1, rsqrt_bc2; unsigned step; };
