@@ -560,6 +560,23 @@ __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, lon
 // swizzle applied to the GLOBAL address of each lane; rows past T are clamped to row T - 1 (a DMA has no bounds check).
 #define GLB_AS __attribute__((address_space(1)))
 
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is wave-uniform; a smaller count than asked for is always safe
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
 __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, int row0, int nrows_img, int T, int wave,
                                            int lane, int nwaves = 8) {
   // image = nrows_img rows of 128 B, tile layout (row r at r * 128, chunk c at ((c ^ swz(r)) << 4))
@@ -592,55 +609,30 @@ __device__ __forceinline__ u32x2 pack_lo(const f32x4& v, const u32x2& pk) {
   return (u32x2){pack2bf(v[0] - h0, v[1] - h1), pack2bf(v[2] - h2, v[3] - h3)};
 }
 
-template <int DH, int RQ>
-__global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
-  resolve_drop(p.drop);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VIT_FWD_STAMP  // diagnostic build only (tools/fwd_stamps.py): where a wave's lifetime goes, one record per wave
+#define FWD_ST_WAVES (1 << 16)
+__device__ unsigned long long g_fwd_st[FWD_ST_WAVES * 8];
+#define FWD_ST(K)                                                                                   \
+  {                                                                                                 \
+    unsigned long long t_;                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    st_[K] = t_ - tprev_;                                                                           \
+    tprev_ = t_;                                                                                    \
+  }
+#else
+#define FWD_ST(K)
+#endif
+
+// The key loop of one wave: RQ 16-row query tiles (fragments qf) against the staged K / V images of a head; running max m,
+// row sums l and the transposed output accumulators ot are the caller's.  pre_pv() runs once, before the first V fragment read.
+template <int DH, int RQ, class PrePV>
+__device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, const bf16x8 (&qf)[RQ][DH / 32], float (&m)[RQ],
+                                            float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int T, float c, const DropCfg& drop, int bh,
+                                            int q00, int l15, int lg, PrePV&& pre_pv) {
   constexpr int TILE = RT * DH * 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  // workgroups go to the XCDs round-robin (blockIdx % 8): deal each XCD a contiguous run of logical ids, so the nsplit
-  // workgroups that stage the SAME head's K / V sit on one XCD, back to back, and the second one finds them in that L2
-  const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int bh = wg / p.nsplit, part = wg - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
-  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
-  const long ld = 3L * p.H * dh;
-  const short* qb = p.qkv + (long)b * T * ld + h * dh;
-  const short* kb_ = qb + p.H * dh;
-  const short* vb = kb_ + p.H * dh;
-  char* Kimg = smem;
-  // only the 16-row blocks that hold keys are staged: 208 rows at T = 197 -> 52 KiB per workgroup, so THREE workgroups
-  // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
-  const int rows_alloc = (T + 15) & ~15;
-  char* Vimg = smem + rows_alloc * (DH * 2);
-  if (DH == 64 && dh == 64) {
-    // no registers, no zero-fill moves, no address arithmetic per chunk: this kernel saturates the VALU (PMC: 3 waves x 33 %
-    // VALU-active per SIMD) and the register-staged form spent ~300 VALU instructions per wave here.  Keys past T are
-    // masked to -inf in the edge tile, so the clamped duplicate rows are never used.
-    const int nwv = blockDim.x >> 6;
-    dma_rows64(Kimg, kb_, ld, 0, rows_alloc, T, wave, lane, nwv);
-    dma_rows64(Vimg, vb, ld, 0, rows_alloc, T, wave, lane, nwv);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
-  }
-  __syncthreads();
-  const int q00 = (part * p.wpw + wave) * RQ * 16;
-  if (q00 >= T) return;  // no barrier after this point
-
-  bf16x8 qf[RQ][DH / 32];
-  float m[RQ], l[RQ];
-  f32x4 ot[RQ][DH / 16];
-#pragma unroll
-  for (int rq = 0; rq < RQ; ++rq) {
-    load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
-    m[rq] = -INFINITY;
-    l[rq] = 0.f;
-#pragma unroll
-    for (int i = 0; i < DH / 16; ++i) ot[rq][i] = zero4();
-  }
-  const float c = p.scale * LOG2E;
-  const unsigned half_cols = (unsigned)((T + 1) >> 1);
-
+  bool first = true;
   // One 64-key tile.  NJ = its 16-key blocks that hold keys (compile-time: the full tiles run a body with no validity test,
   // no -inf fills and no edge select at all; the LAST tile runs the body for its own block count, so a T = 197 head does
   // 3 x 4 + 1 blocks of softmax / dropout work instead of 4 x 4), EDGE = the last block straddles T (per-key select).
@@ -694,12 +686,12 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
       l[rq] = l[rq] * alpha + ls;
 #pragma unroll
       for (int i = 0; i < DH / 16; ++i) ot[rq][i] *= alpha;
-      if (p.drop.thr) {
+      if (drop.thr) {
         // keep <=> the element's 16-bit draw >= thr: the high draw by ONE unsigned compare of the whole word against thr << 16,
         // the low draw after one shift; dropped probabilities become 0 by a select, and the 1 / (1 - p) of the kept ones is
         // applied once per row at the end (it rides in `inv`): 2.5 instead of 4 VALU per element in this VALU-bound kernel
-        const unsigned rkey = drop_rowkey(p.drop, (unsigned long long)bh * T + (q00 + rq * 16 + l15));
-        const unsigned thr16 = p.drop.thr << 16;
+        const unsigned rkey = drop_rowkey(drop, (unsigned long long)bh * T + (q00 + rq * 16 + l15));
+        const unsigned thr16 = drop.thr << 16;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const unsigned key = kb + j * 16 + lg * 4;
@@ -711,10 +703,12 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
         }
       }
     }
+    if (first) {  // first tile only (uniform): the caller's hook (resident kernel: V in and published) before the first V read
+      pre_pv();
+      first = false;
+    }
 #pragma unroll
     for (int u = 0; u < (NJ + 1) / 2; ++u) {
-      constexpr bool dummy = false;
-      (void)dummy;
       const bool two = 2 * u + 1 < NJ;  // compile-time after unrolling
       bf16x8 pf[RQ];
 #pragma unroll
@@ -740,13 +734,21 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
     else if (nj == 3) tile(integral_constant<int, 3>{}, integral_constant<bool, true>{}, nfull);
     else tile(integral_constant<int, 4>{}, integral_constant<bool, true>{}, nfull);
   }
+}
+
+// Normalise, store the context rows (+ their rounding residual) and the row statistics of one wave's query tiles.
+template <int DH, int RQ, bool FULL = false>  // FULL: dh == DH is known at compile time (no row-per-lane store path compiled)
+__device__ __forceinline__ void fwd_finish(const AttnArgs& p, const float (&m)[RQ], const float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int b,
+                                           int h, int bh, int q00, float c, int l15, int lg) {
+  const int T = p.T, dh = p.dh;
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
+    if (q00 + rq * 16 >= T) continue;  // uniform: a tile with no row below T has nothing to store
     const float lt = grp4_sum(l[rq]);
     const int q = q00 + rq * 16 + l15;
     const float inv = (p.drop.thr ? p.drop.scale : 1.0f) / lt;  // the kept probabilities' 1 / (1 - p) rides here
     short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
-    if (dh == DH && (DH % 32) == 0) {
+    if ((FULL || dh == DH) && (DH % 32) == 0) {
       // 16-byte stores: two adjacent 16-column tiles per instruction (row-per-lane stores are issue-bound)
 #pragma unroll
       for (int dp = 0; dp < DH / 32; ++dp) {
@@ -774,6 +776,122 @@ __global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
     }
     if (q < T && lg == 0) p.lse[(long)bh * T + q] = (m[rq] * c + log2f(lt)) * LN2;
   }
+}
+
+// DMA: dh == DH == 64 (compile-time, so that the untracked-load prologue below shares no control flow with tracked loads: the
+// compiler waits vmcnt(0) wherever a tracked load MIGHT be pending, and would drain the V image with it)
+template <int DH, int RQ, bool DMA>
+__global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
+  resolve_drop(p.drop);
+#ifdef VIT_FWD_STAMP
+  unsigned long long tprev_, st_[5] = {0, 0, 0, 0, 0};
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
+  const unsigned long long tstart_ = tprev_;
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroups go to the XCDs round-robin (blockIdx % 8): deal each XCD a contiguous run of logical ids, so the nsplit
+  // workgroups that stage the SAME head's K / V sit on one XCD, back to back, and the second one finds them in that L2
+  const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int bh = wg / p.nsplit, part = wg - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
+  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const long ld = 3L * p.H * dh;
+  const short* qb = p.qkv + (long)b * T * ld + h * dh;
+  const short* kb_ = qb + p.H * dh;
+  const short* vb = kb_ + p.H * dh;
+  char* Kimg = smem;
+  // only the 16-row blocks that hold keys are staged: 208 rows at T = 197 -> 52 KiB per workgroup, so THREE workgroups
+  // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
+  const int rows_alloc = (T + 15) & ~15;
+  char* Vimg = smem + rows_alloc * (DH * 2);
+  const int q00 = (part * p.wpw + wave) * RQ * 16;
+  bf16x8 qf[RQ][DH / 32];
+  float m[RQ], l[RQ];
+  f32x4 ot[RQ][DH / 16];
+  // The wave's Q rows first (plain loads, oldest in the vmcnt order), then K, then V: the waits below are counted, so that
+  // the three latencies overlap and the first tile's scores start when K is in (stamps, r03: a wave spent 30 % of its life
+  // waiting for K + V together and another 10 % for Q fragments requested only after that)
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    if constexpr (DMA) {
+      // loads the compiler does not track (it would wait vmcnt(0) at their first use and drain V with them): rows past T read
+      // the last row again (never stored); the counted wait below covers them -- they are the oldest operations in flight
+#pragma unroll
+      for (int s = 0; s < DH / 32; ++s) {
+        i32x4 v;
+        const short* src = qb + (long)min(q00 + rq * 16 + l15, T - 1) * ld + s * 32 + lg * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+        qf[rq][s] = __builtin_bit_cast(bf16x8, v);
+      }
+    } else {
+      load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
+    }
+  }
+  bool v_pending = false;
+  if constexpr (DMA) {
+    // no registers, no zero-fill moves, no address arithmetic per chunk: this kernel saturates the VALU (PMC: 3 waves x 33 %
+    // VALU-active per SIMD) and the register-staged form spent ~300 VALU instructions per wave here.  Keys past T are
+    // masked to -inf in the edge tile, so the clamped duplicate rows are never used.
+    const int nwv = blockDim.x >> 6, npc = rows_alloc >> 3;
+    dma_rows64(Kimg, kb_, ld, 0, rows_alloc, T, wave, lane, nwv);
+    dma_rows64(Vimg, vb, ld, 0, rows_alloc, T, wave, lane, nwv);
+    wait_vmcnt_dyn(wave < npc ? (npc - wave + nwv - 1) / nwv : 0);  // all but this wave's V pieces: Q and K are in
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+      for (int s = 0; s < DH / 32; ++s) asm volatile("" : "+v"(qf[rq][s]));  // uses of Q stay behind the wait
+    __builtin_amdgcn_sched_barrier(0);
+    v_pending = true;
+  } else {
+    load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
+  }
+  FWD_ST(0)  // Q + K landed (this wave's pieces)
+  __syncthreads();
+  FWD_ST(1)  // barrier
+  if (q00 >= T) {  // a wave with no query rows: it still owes the workgroup its V pieces and the barrier that publishes them
+    if (v_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    return;
+  }
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq) {
+    m[rq] = -INFINITY;
+    l[rq] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH / 16; ++i) ot[rq][i] = zero4();
+  }
+  const float c = p.scale * LOG2E;
+#ifdef VIT_FWD_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::"v"(qf[0][0]), "v"(qf[RQ - 1][DH / 32 - 1]));
+#endif
+  FWD_ST(2)  // Q fragments in registers
+
+  fwd_keyloop<DH, RQ>(Kimg, Vimg, qf, m, l, ot, T, c, p.drop, bh, q00, l15, lg, [&]() {
+    if (v_pending) {  // V in and published before its first fragment read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  });
+  FWD_ST(3)  // key loop
+  fwd_finish<DH, RQ, DMA>(p, m, l, ot, b, h, bh, q00, c, l15, lg);
+#ifdef VIT_FWD_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FWD_ST(4)  // normalise + stores retired
+  {
+    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && wid < FWD_ST_WAVES) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) g_fwd_st[wid * 8 + k] = st_[k];
+      g_fwd_st[wid * 8 + 5] = tstart_;
+      g_fwd_st[wid * 8 + 6] = tprev_;
+      g_fwd_st[wid * 8 + 7] = 1;
+    }
+  }
+#endif
 }
 
 // Dropout keep FLAGS of 4 consecutive query rows at ONE key for the key-owner orientation of the backward kernels, from the
@@ -1770,23 +1888,6 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 // T - 1, their probabilities are zero through lse = +inf (queries) / +inf added on the key side.
 // LDS: ring 3 x 16 KiB + lse staging 3 KiB + 2 K images + V image + 2 dS images [R][32] + statistics = 156 KiB at R = 208.
 // dh = 64, 64 <= T <= 208.  Deterministic, no atomics (basemodule.py:250).
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is wave-uniform; a smaller count than asked for is always safe
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-  }
-}
 // one LDS-DMA piece: 8 rows x 128 B (image rows row_img .. + 7 of a [rows][64] bf16 matrix whose image row 0 is global row
 // grow0) into 1 KiB of consecutive LDS; SWZ: the tile image's XOR swizzle, applied to the lane's GLOBAL chunk
 template <bool SWZ>
@@ -2216,6 +2317,18 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   }
 #endif
 }
+#ifdef VIT_FWD_STAMP
+}  // namespace vit
+extern "C" int vit_debug_fwd_stamps(unsigned long long* host, int reset) {  // host: FWD_ST_WAVES * 8 words
+  if (reset) {
+    void* d = nullptr;
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(vit::g_fwd_st)) != hipSuccess) return -1;
+    return (int)hipMemset(d, 0, sizeof(unsigned long long) * FWD_ST_WAVES * 8);
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vit::g_fwd_st), sizeof(unsigned long long) * FWD_ST_WAVES * 8);
+}
+namespace vit {
+#endif
 #ifdef VIT_PIPE_STAMP
 }  // namespace vit
 extern "C" int vit_debug_pipe_stamps(unsigned long long* host64) {
@@ -2804,7 +2917,10 @@ int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo,
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop_h(h, dropout_p, seed, site);
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
-    DISPATCH_RES(attn_fwd_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), (hipStream_t)stream, rc);
+    const size_t img = 2 * (size_t)((T + 15) & ~15) * 2;  // K + V images: rows x dh_padded x 2 bytes each
+    if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream);
+    else if (a.dh <= 32) rc = launch_res<attn_fwd_res_kernel<32, RES_RQ, false>>(a, img * 32, (hipStream_t)stream);
+    else rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, false>>(a, img * 64, (hipStream_t)stream);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
