@@ -63,6 +63,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "gemm_half_tail": 1 (default) = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
  *                and plain dX epilogues; 2 = the GELU epilogue too) run in a second launch as half tiles, two workgroups per
  *                tile; 0 = one launch.
+ *   "gemm_split_tail": 1 (default) = a SHORT tail (at most a quarter of the workgroup slots) of a long-K product runs as K-slices of
+ *                whole tiles + a small reduce-and-epilogue kernel instead of half tiles (ViT-L: 36 of 292 tiles at K = 3072 /
+ *                4096); needs 4 x slices x 65536 bytes of workspace per tail tile, else the half-tile launch is used; 0 = never.
  *   "gemm_balance_wgs": 1 (default) = a multi-round ping-pong GEMM launches ceil(tiles / rounds) workgroups instead of 256
  *                (same makespan in tile-times, idle CUs instead of CUs that idle for the last round); 0 = always 256.
  *   "gemm_pp_slots": 8 (the only value since round 2: the 10-slot ring, 96 KiB of operand loads in flight per CU, measured

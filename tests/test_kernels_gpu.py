@@ -691,6 +691,38 @@ def test_gemm_half_tile_tail(dev, M, N, K):
     assert rel(outs[1][2], dy.float() @ W2.float()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(256 * 73, 1024, 4096), (256 * 73, 1024, 3072), (256 * 70, 1024, 4096)])
+def test_gemm_split_k_tail(dev, M, N, K):
+    """A short tail of a long-K product (ViT-L: 292 tiles = one round of 256 + 36; 280 = 256 + 24) runs as K-slices of whole
+    tiles + a reduce-and-epilogue kernel.  Same dropout mask and bias as the half-tile form; the sums are ordered differently
+    (slices of K added in f32), so the bf16 outputs agree to rounding, and both agree with the fp32 product."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    x, W = bf(randn((M, K), dev, 160)), bf(randn((N, K), dev, 161, 0.05))
+    bias = randn((N,), dev, 162)
+    dy, W2 = bf(randn((M, K), dev, 163)), bf(randn((K, N), dev, 164, 0.05))
+    drop = (0.1, 5, 6)
+    outs = {}
+    for mode in (0, 1):
+        _cabi.set_option("gemm_split_tail", mode)
+        try:
+            outs[mode] = (vf.gemm(x, W, M=M, N=N, K=K, bias=bias, dropout=drop),
+                          vf.gemm(x, W, M=M, N=N, K=K, bias=bias),
+                          vf.gemm(dy, W2, M=M, N=N, K=K, b_trans=True))
+        finally:
+            _cabi.set_option("gemm_split_tail", 1)
+    tail = slice(M - 256 * 12, M)  # rows of the last tiles: the ones that went through the slices
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a[:M - 256 * 12], b[:M - 256 * 12])  # the full rounds are the same launch either way
+        assert rel(a[tail], b[tail]) < 3e-3
+    assert ((outs[0][0] == 0) == (outs[1][0] == 0)).all()  # same dropout mask
+    assert rel(outs[1][1], x.float() @ W.float().t() + bias) < 4e-3
+    assert rel(outs[1][2], dy.float() @ W2.float()) < 4e-3
+    assert rel(outs[1][1][tail], (x.float() @ W.float().t() + bias)[tail]) < 4e-3
+    assert rel(outs[1][2][tail], (dy.float() @ W2.float())[tail]) < 4e-3
+
+
 @pytest.mark.parametrize("B,H,T,dh", [(1, 2, 197, 64), (1, 2, 577, 64), (1, 1, 640, 64)])
 def test_attention_delta_residual(dev, B, H, T, dh):
     """vit_attention_fwd_lo / vit_attention_bwd_lo: with value rows that share a large common component (what deep layers

@@ -15,7 +15,7 @@ struct vit_ctx {
 
 namespace vit {
 
-extern int g_gemm2_mode, g_pp_slots, g_balance_wgs, g_half_tail, g_grp2;  // gemm2.hip
+extern int g_gemm2_mode, g_pp_slots, g_balance_wgs, g_half_tail, g_split_tail, g_grp2;  // gemm2.hip
 extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn32_mfma;  // attention.hip
 
 static thread_local char g_err[512] = "";
@@ -111,6 +111,10 @@ int vit_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_res_max_t") == 0) {
     vit::g_attn_res_max_t = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "gemm_split_tail") == 0) {
+    vit::g_split_tail = value;
     return VIT_OK;
   }
   if (strcmp(name, "gemm_half_tail") == 0) {

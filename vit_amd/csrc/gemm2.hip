@@ -53,6 +53,7 @@ struct Gemm2Args {
   float* colsum_part;  // ping-pong kernel, bf16 epilogues: [tiles_m * 2][N] per-wave-row column sums of C, or NULL
   int tile_limit;      // ping-pong kernel: walk only the first tile_limit tiles (0 = all); the half-tile kernel takes the rest
   int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
+  int slab_tiles;  // split-K over the tail tiles: the slab is compact, [split][tile - tail_first][256][256] f32 (0: [split][M][N])
   int grp2;  // ping-pong kernel: XCDs 0-3 walk the lower half of the N-tiles, XCDs 4-7 the upper half (see tile_coords)
 #ifdef VIT_PP_STAMP
   unsigned long long* stamps;  // diagnostic build: [8 waves][8] summed s_memtime deltas of workgroup `stamp_block`
@@ -166,7 +167,14 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
   if (FAST == 7) {
     // f32 out: a lane owns 4 consecutive columns of rows rr*4 + lane/16 (16-byte stores, 256-byte row segments)
     float* cf = p.splits > 1 ? p.slab + (long)split * p.M * p.N : (float*)p.C;
-    const long ldc = p.splits > 1 ? (long)p.N : p.ldc;
+    long ldc = p.splits > 1 ? (long)p.N : p.ldc;
+    if (p.slab_tiles) {  // tail tiles only: one 256 x 256 block per (K-slice, tile)
+      const int tl = (m0 >> 8) * p.tiles_n + (n0 >> 8) - p.tail_first;
+      cf = p.slab + ((long)split * p.slab_tiles + tl) * 65536;
+      ldc = 256;
+      m0 &= 255;
+      n0 &= 255;
+    }
     const int n = n0 + l15 * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
       tn = g * hn + (u - tm * hn);
       return;
     }
-    const int t = p.lin_split ? bx : round0 + pos;
+    const int t = p.lin_split ? p.tail_first + bx : round0 + pos;  // tail_first: 0 unless this launch is the tail's K-slices
     tm = t / p.tiles_n;
     tn = t - tm * p.tiles_n;
   };
@@ -974,6 +982,54 @@ static int launch_half_cfg(const Gemm2Args& a, int epi, hipStream_t st) {
   return launch_half<0, 1, 6>(a, st);
 }
 
+// Sum of the tail tiles' K-slices + the epilogue the ping-pong kernel would have run (EPI 3: +bias, dropout -> bf16; 6: plain ->
+// bf16): block = 8 rows x 256 columns of one tile, a thread owns 8 consecutive columns; slices are added in index order.
+template <int EPI>
+__global__ __launch_bounds__(256) void tail_reduce_kernel(Gemm2Args p) {
+  resolve_drop(p.drop);
+  const int tl = blockIdx.x >> 5, r = ((blockIdx.x & 31) << 3) + (threadIdx.x >> 5), cg = threadIdx.x & 31;
+  const int t = p.tail_first + tl, tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+  const float* src = p.slab + (long)tl * 65536 + r * 256 + cg * 8;
+  f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+  for (int s = 1; s < p.splits; ++s) {
+    const float* q = src + (long)s * p.slab_tiles * 65536;
+    v0 += *(const f32x4*)q;
+    v1 += *(const f32x4*)(q + 4);
+  }
+  const long m = (long)tm * 256 + r;
+  const int n = tn * 256 + cg * 8;
+  float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  if (EPI == 3) {
+    if (p.bias) {
+      const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] += b0[i];
+        o[4 + i] += b1[i];
+      }
+    }
+    if (p.drop.thr) {
+      const unsigned half_cols = (unsigned)(p.N >> 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float k0, k1;
+        drop_pair(p.drop, (unsigned long long)m, half_cols, (unsigned)n + 2 * i, k0, k1);
+        o[2 * i] *= k0;
+        o[2 * i + 1] *= k1;
+      }
+    }
+  }
+  const u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+  *(u32x4*)(p.C + (m * p.ldc + n) * 2) = pk;
+}
+static int launch_tail_reduce(const Gemm2Args& a, int epi, hipStream_t st) {
+  if (epi == 3) hipLaunchKernelGGL(tail_reduce_kernel<3>, dim3(a.slab_tiles * 32), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(tail_reduce_kernel<6>, dim3(a.slab_tiles * 32), dim3(256), 0, st, a);
+  VIT_LAUNCH_CHECK();
+  return VIT_OK;
+}
+
+int g_split_tail = 1;  // vit_set_option("gemm_split_tail"): K-slices instead of half tiles for a short tail of a long-K GEMM
 int g_grp2 = 1;  // vit_set_option("gemm_ngroups"): 1 = two N-groups for weights larger than an L2 (see tile_coords)
 int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
@@ -1002,7 +1058,12 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
   if (epi == 4) return launch_stag<0, 0, 4>(a, grid, st);
   if (epi == 5) return launch_stag<0, 1, 5>(a, grid, st);
   if (epi == 6) return launch_stag<0, 1, 6>(a, grid, st);
-  if (epi == 7) return launch_stag<1, 1, 7>(a, grid, st);
+  if (epi == 7) {
+    if (at && bt) return launch_stag<1, 1, 7>(a, grid, st);
+    if (!at && !bt) return launch_stag<0, 0, 7>(a, grid, st);  // the next two: K-slices of a forward / dX GEMM's tail tiles
+    if (!at && bt) return launch_stag<0, 1, 7>(a, grid, st);
+    return VIT_ERR_ARG;
+  }
   if (!at && !bt) return launch_stag<0, 0, 0>(a, grid, st);
   if (!at && bt) return launch_stag<0, 1, 0>(a, grid, st);
   if (at && !bt) return launch_stag<1, 0, 0>(a, grid, st);
@@ -1074,7 +1135,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.slab = (float*)ws;
   }
   a.nblk = std::min(ntile, slots);
-  a.tile_limit = 0; a.tail_first = 0; a.tail_n = 0;
+  a.tile_limit = 0; a.tail_first = 0; a.tail_n = 0; a.slab_tiles = 0;
   a.bias = d->bias;
   a.aux_in = (const short*)d->aux_in; a.aux_out = (short*)d->aux_out; a.ldaux = d->ldaux;
   a.residual = d->residual; a.ldres = d->ldres;
@@ -1138,6 +1199,21 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.tail_first = ntile - half_tail;
     a.tail_n = half_tail;
   }
+  // A SHORT tail of a LONG-K product (ViT-L: 36 of 292 tiles, K = 3072 / 4096) runs as K-slices instead: every workgroup does a
+  // whole 256 x 256 tile at the main loop's efficiency over K / s, s = slots / tail, and a small kernel adds the slices and runs
+  // the epilogue.  The f32 partials cost 2 x s x 256 KiB of traffic per tile, so it only pays from s >= 4 (priced in DESIGN
+  // section 7: a wash at ViT-B's 79-tile tails with s = 3).
+  int st_splits = 0, st_kps = 0;
+  if (half_tail && g_split_tail && (epi5 == 3 || epi5 == 6)) {
+    const int s_ = slots / half_tail;
+    if (s_ >= 4 && ktiles / s_ >= 6) {
+      st_kps = cdiv(ktiles, s_) * 64;
+      st_splits = cdiv(d->K, st_kps);
+      size_t wsb = 0;
+      void* ws = ctx_workspace(h, &wsb);
+      if (!ws || wsb < (size_t)st_splits * half_tail * 65536 * sizeof(float)) st_splits = 0;
+    }
+  }
   if (d->colsum_out && cfg == 5 && (epi5 == 3 || epi5 == 5 || epi5 == 6)) {
     size_t wsb = 0;
     void* ws = ctx_workspace(h, &wsb);
@@ -1148,7 +1224,20 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, 8);
   }
   int r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
-  if (r == VIT_OK && half_tail) r = launch_half_cfg(a, epi5, st);
+  if (r == VIT_OK && half_tail && st_splits > 1) {
+    Gemm2Args b = a;
+    size_t wsb = 0;
+    b.slab = (float*)ctx_workspace(h, &wsb);
+    b.slab_tiles = half_tail;
+    b.splits = st_splits; b.k_per_split = st_kps;
+    b.lin_split = 1; b.grp2 = 0;
+    b.tile_limit = half_tail;  // the kernel's tile count; tile ids are tail_first + 0 .. half_tail - 1
+    b.nblk = half_tail;
+    r = launch_stag_cfg(b, 0, d->b_trans, 7, dim3(half_tail * st_splits), st);
+    if (r == VIT_OK) r = launch_tail_reduce(b, epi5, st);
+  } else if (r == VIT_OK && half_tail) {
+    r = launch_half_cfg(a, epi5, st);
+  }
   if (r == VIT_OK && a.colsum_part) {
     r = launch_reduce_partials(a.colsum_part, a.tiles_m * 2, d->N, d->colsum_out, d->N, d->colsum_out, 0, st);
     g_colsum_fused = 1;
