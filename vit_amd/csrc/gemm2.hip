@@ -1206,7 +1206,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
   int st_splits = 0, st_kps = 0;
   if (half_tail && g_split_tail && (epi5 == 3 || epi5 == 6)) {
     const int s_ = slots / half_tail;
-    if (s_ >= 4 && ktiles / s_ >= 6) {
+    if (s_ >= (g_split_tail >= 2 ? 3 : 4) && ktiles / s_ >= 6) {  // gemm_split_tail = 2: from 3 slices (ViT-B's 79-tile tails; measured a wash)
       st_kps = cdiv(ktiles, s_) * 64;
       st_splits = cdiv(d->K, st_kps);
       size_t wsb = 0;
