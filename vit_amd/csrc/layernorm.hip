@@ -6,6 +6,10 @@
 
 #include "common.h"
 
+#ifndef VIT_LNF_BLOCKS4
+#define VIT_LNF_BLOCKS4 1792
+#endif
+
 namespace vit {
 
 void* ctx_workspace(vit_handle h, size_t* bytes);
@@ -97,11 +101,20 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   const int nvec = D >> 2;
   const float invD = 1.0f / (float)D;
-  f32x4 gam[NV], dg[NV], db[NV], dbias[FUSE ? NV : 1];
+  // gamma: in registers up to D = 768; from D = 1024 (NV = 4, ViT-L) in the LDS behind the reduction buffer -- with three
+  // accumulator sets of NV x 4 registers the fused form spilled 14 registers per lane at 128 VGPRs (4 waves per SIMD) and its
+  // scratch traffic sat inside the row loop (r03: 4.2 TB/s at ViT-L against 6.0 TB/s at ViT-B)
+  constexpr bool GAM_LDS = NV >= 4 && FUSE != 0;
+  float* gam_s = red + 4 * NP * D;
+  f32x4 gam[GAM_LDS ? 1 : NV], dg[NV], db[NV], dbias[FUSE ? NV : 1];
+  if (GAM_LDS) {
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) *(f32x4*)(gam_s + 4 * i) = *(const f32x4*)(gamma + 4 * i);
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
-    gam[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!GAM_LDS) gam[i] = (c < nvec) ? *(const f32x4*)(gamma + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
     dg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     db[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (FUSE) dbias[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
           d = *(const f32x4*)((const float*)dy + (long)row * D + 4 * c);
         }
         xh[i] = (*(const f32x4*)(x + (long)row * D + 4 * c) - mu) * rs;
-        g[i] = d * gam[i];
+        g[i] = d * (GAM_LDS ? *(const f32x4*)(gam_s + 4 * c) : gam[GAM_LDS ? 0 : i]);
         dg[i] += d * xh[i];
         db[i] += d;
         s1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
@@ -204,8 +217,9 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const void* __restrict__ d
 template <int OUT_BF16, int RES>
 static int ln_fwd_dispatch(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
                            int D, float eps, hipStream_t st, const void* delta = nullptr, float* xsum = nullptr) {
-  const int blocks = std::min(cdiv(rows, 4), 2048);
   const int nv = cdiv(D, 256);
+  // one round of resident 4-wave blocks: 8 per CU up to D = 768 (<= 64 VGPRs), 7 at D = 1024 (72 VGPRs)
+  const int blocks = std::min(cdiv(rows, 4), nv >= 4 ? VIT_LNF_BLOCKS4 : 2048);
 #define LAUNCH(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, OUT_BF16, RES>), dim3(blocks), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, D, eps, delta, xsum)
   if (nv <= 1) LAUNCH(1);
   else if (nv <= 2) LAUNCH(2);
@@ -223,7 +237,7 @@ static int ln_bwd_dispatch(const void* dy, const float* x, const float* g, const
                            const float* dres, float* dx, float* part, int rows, int D, int blocks, int threads,
                            void* dyn, DropCfg drop, hipStream_t st) {
   const int nv = cdiv(D, 256);
-  const size_t sh = (size_t)4 * (FUSE ? 3 : 2) * D * sizeof(float);
+  const size_t sh = (size_t)4 * (FUSE ? 3 : 2) * D * sizeof(float) + (FUSE && nv >= 4 ? (size_t)D * sizeof(float) : 0);
   if (sh > 64 * 1024) { set_error("vit_layernorm_bwd: D=%d needs %zu bytes of LDS", D, sh); return VIT_ERR_UNSUPPORTED; }
 #define LAUNCH(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, DY_BF16, FUSE>), dim3(blocks), dim3(threads), sh, st, dy, x, g, mean, rstd, dres, dx, part, rows, D, dyn, drop)
   if (nv <= 1) LAUNCH(1);
