@@ -632,12 +632,12 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
                                             float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int T, float c, const DropCfg& drop, int bh,
                                             int q00, int l15, int lg, PrePV&& pre_pv) {
   constexpr int TILE = RT * DH * 2;
-  bool first = true;
   // One 64-key tile.  NJ = its 16-key blocks that hold keys (compile-time: the full tiles run a body with no validity test,
   // no -inf fills and no edge select at all; the LAST tile runs the body for its own block count, so a T = 197 head does
   // 3 x 4 + 1 blocks of softmax / dropout work instead of 4 x 4), EDGE = the last block straddles T (per-key select).
   // Blocks that are left out would have contributed exp(-inf) = 0 to the row sums and zero rows to P V: same results.
-  auto tile = [&](auto njc, auto edgec, int kt) {
+  // HOOK (compile-time): the caller's pre_pv() runs between this tile's scores and its first V fragment read.
+  auto tile = [&](auto njc, auto edgec, auto hookc, int kt) {
     constexpr int NJ = decltype(njc)::value;
     constexpr bool EDGE = decltype(edgec)::value;
     const int kb = kt * RT;
@@ -703,10 +703,7 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
         }
       }
     }
-    if (first) {  // first tile only (uniform): the caller's hook (resident kernel: V in and published) before the first V read
-      pre_pv();
-      first = false;
-    }
+    if constexpr (decltype(hookc)::value) pre_pv();
 #pragma unroll
     for (int u = 0; u < (NJ + 1) / 2; ++u) {
       const bool two = 2 * u + 1 < NJ;  // compile-time after unrolling
@@ -724,15 +721,20 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
     }
   };
   using std::integral_constant;
+  using no = integral_constant<bool, false>;
+  using yes = integral_constant<bool, true>;
   const int nfull = T / RT;
-  for (int kt = 0; kt < nfull; ++kt) tile(integral_constant<int, 4>{}, integral_constant<bool, false>{}, kt);
+  // the first tile is peeled (the hook sits inside it); a sequence shorter than one full tile runs the hook before its only tile
+  if (nfull > 0) tile(integral_constant<int, 4>{}, no{}, yes{}, 0);
+  else pre_pv();
+  for (int kt = 1; kt < nfull; ++kt) tile(integral_constant<int, 4>{}, no{}, no{}, kt);
   const int rem = T - nfull * RT;
   if (rem > 0) {
     const int nj = (rem + 15) >> 4;
-    if (nj == 1) tile(integral_constant<int, 1>{}, integral_constant<bool, true>{}, nfull);
-    else if (nj == 2) tile(integral_constant<int, 2>{}, integral_constant<bool, true>{}, nfull);
-    else if (nj == 3) tile(integral_constant<int, 3>{}, integral_constant<bool, true>{}, nfull);
-    else tile(integral_constant<int, 4>{}, integral_constant<bool, true>{}, nfull);
+    if (nj == 1) tile(integral_constant<int, 1>{}, yes{}, no{}, nfull);
+    else if (nj == 2) tile(integral_constant<int, 2>{}, yes{}, no{}, nfull);
+    else if (nj == 3) tile(integral_constant<int, 3>{}, yes{}, no{}, nfull);
+    else tile(integral_constant<int, 4>{}, yes{}, no{}, nfull);
   }
 }
 
