@@ -526,3 +526,67 @@ def test_fused_adamw_refuses_replaced_grad_under_reducer(dev):
     before = p.detach().clone()
     opt.step()
     assert not torch.equal(before, p)
+
+
+def test_full_size_vit_b_training_step(dev):
+    """The BASELINE configuration itself under -m gpu ('C3 at the full B = 256 runs only in bench.py'):
+    ViT-B/16 224^2 restated, B = 256, bf16-mixed, one rank.  Size-independent properties at full size:
+    (1) with dropout off the step is a deterministic function of (weights, batch): two runs from the same seed give the same
+        three losses and the same clipped gradient norms bit for bit (reference: deterministic=True, src/basemodule.py:250);
+    (2) with dropout off the training-mode loss of step 0 is the evaluation-mode loss of the same weights and batch;
+    (3) the loss is a mean over samples: L(256) = mean of the four quarter-batch losses to fp32 rounding (per-sample
+        independence: nothing in the path mixes samples), and of the two half-batch losses to bf16 rounding (that shape takes
+        the split-K tail path);
+    (4) with dropout on, three steps stay finite, clip to 0.5 and move every trainable tensor."""
+    import vit_amd.functional  # noqa: F401
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    def cfg(B):
+        return {
+            "model": dict(name="vit", task_type="reg", image_size=50176, patch_size=256, hidden_size=768, num_hidden_layers=12,
+                          num_attention_heads=12, stride_size=256, proj_fn="SW"),
+            "train": dict(batch_size=B, ep=1, precision="bf16-mixed"),
+            "loss": {"name": "mae"}, "opt": {"type": "AdamW", "lr": 1e-3}, "data": {"param": "log_g"},
+            "noise": {"noise_level": 0},
+        }
+
+    g = torch.Generator().manual_seed(1234)
+    flux, err, lab = torch.randn(256, 50176, generator=g).cuda(), (0.1 * torch.rand(256, 50176, generator=g)).cuda(), \
+        torch.rand(256, generator=g).cuda()
+
+    def run(B, dropout, steps, sl=slice(None)):
+        seed_everything(42)
+        module = ViTLModule(config=cfg(B))
+        if not dropout:
+            module.model.config.hidden_dropout_prob = 0.0
+            module.model.config.attention_probs_dropout_prob = 0.0
+        trainer = Trainer(cfg(B)["train"], device=torch.device("cuda", 0), verbose=False)
+        trainer._setup(module)
+        module.eval()
+        with torch.no_grad():
+            ev = float(module(flux[sl], labels=lab[sl]))
+        module.train()
+        w0 = {k: v.detach().clone() for k, v in module.model.state_dict().items()}
+        out = []
+        for i in range(steps):
+            out.append((float(trainer.training_step(module, (flux[sl], err[sl], lab[sl]), i)),
+                        float(trainer.optimizer.last_grad_norm)))
+        return ev, out, w0, module
+
+    ev_a, a, _, _ = run(256, False, 3)
+    ev_b, b, _, _ = run(256, False, 3)
+    assert a == b and ev_a == ev_b, (a, b)                                   # (1)
+    assert abs(a[0][0] - ev_a) <= 1e-6 * max(1.0, abs(ev_a)), (a[0][0], ev_a)  # (2)
+    quarters = [run(64, False, 0, slice(i, i + 64))[0] for i in range(0, 256, 64)]
+    assert abs(sum(quarters) / 4 - ev_a) <= 2e-6 * max(1.0, abs(ev_a)), (quarters, ev_a)  # (3): same kernels, same sums per row
+    # B = 128 is 99 row tiles: 297 tiles = one round + 41, a short tail -> FC2 / dX run their tail tiles as K-slices
+    # (gemm_split_tail), whose f32 partial sums are added in another order: equal to bf16 rounding, not bit for bit
+    ev_lo, _, _, _ = run(128, False, 0, slice(0, 128))
+    ev_hi, _, _, _ = run(128, False, 0, slice(128, 256))
+    assert abs(0.5 * (ev_lo + ev_hi) - ev_a) <= 3e-3 * abs(ev_a), (ev_lo, ev_hi, ev_a)
+    _, d, w0, module = run(256, True, 3)
+    assert all(np.isfinite(l) and np.isfinite(n) for l, n in d), d           # (4)
+    moved = [k for k, v in module.model.state_dict().items() if not torch.equal(v, w0[k])]
+    frozen = [k for k in w0 if k not in moved]
+    assert all("pooler" in k for k in frozen), frozen  # the pooler is never used (SURVEY section 8 e): everything else moved
