@@ -182,7 +182,8 @@ def attn_ref(qkv, B, H, T, dh, scale, mask=None):
 # T mod 64 = 1, 5, 44, 0, 26, 56: the resident forward runs its last key tile in a body for 1, 3, (none), 2, 4 sixteen-key blocks
 ATT_SHAPES = [(2, 2, 129, 16), (2, 3, 5, 64), (2, 4, 197, 64), (1, 2, 300, 32), (1, 1, 70, 128), (1, 2, 64, 64), (1, 2, 90, 64),
               (1, 2, 120, 32), (1, 1, 577, 64),
-              (1, 2, 1025, 16), (1, 1, 640, 64)]  # the last two: past the resident kernels (stride sweeps reach T ~ 4k)
+              (1, 2, 1025, 16), (1, 1, 640, 64),  # these two: past the resident kernels
+              (1, 2, 4034, 16), (1, 1, 4034, 64)]  # the stride sweep's longest sequences (configs/sweep.yaml: S = 1 at L = 4096, P = 64)
 
 
 @pytest.mark.parametrize("B,H,T,dh", ATT_SHAPES)
