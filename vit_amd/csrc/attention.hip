@@ -783,7 +783,7 @@ __device__ __forceinline__ void fwd_finish(const AttnArgs& p, const float (&m)[R
 // DMA: dh == DH == 64 (compile-time, so that the untracked-load prologue below shares no control flow with tracked loads: the
 // compiler waits vmcnt(0) wherever a tracked load MIGHT be pending, and would drain the V image with it)
 template <int DH, int RQ, bool DMA>
-__global__ __launch_bounds__(512, 3) void attn_fwd_res_kernel(AttnArgs p) {
+__global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
 #ifdef VIT_FWD_STAMP
   unsigned long long tprev_, st_[5] = {0, 0, 0, 0, 0};
@@ -2029,9 +2029,6 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   int hm = 0, pm = -3, h0 = 0, p0 = -2, h1 = 0, p1 = -1, h2 = 0, p2 = 0;
   PipeHead Hm = head_of(0), H0 = Hm, H1 = Hm, H2 = Hm, Hn = Hm;
   long q2 = qoff_of(H2), c2 = coff_of(H2), qn = q2;  // element offsets of heads H2 / Hn: 64-bit products, once per head
-#ifdef VIT_PIPE_PRIO  // experiment: the second-dispatched half (waves 4-7) loses issue arbitration to the older half
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 #ifdef VIT_PIPE_STAMP
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev_)::"memory");
@@ -2349,6 +2346,7 @@ static bool persist_fits(int T, int dh) {
 // vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent form where it fits
 // (dh 64, T <= 224), 4 (default) = the pair-pipelined form where it fits (dh 64, 64 <= T <= 208), else 3, else 1
 int g_attn_bwd_fused = 4;
+int g_attn_fwd_waves = 12;  // vit_set_option("attn_fwd_waves"): most waves per workgroup of the resident forward (8 or 12)
 
 static bool fused_fits(int T, int dh) {
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
@@ -2368,15 +2366,19 @@ static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged row
   return 2 * rows * dhp * 2 + 3 * rows * 4 <= 160 * 1024;
 }
 
-static void res_geometry(int T, int* nsplit, int* wpw) {
+// max_waves: 8 for the backward kernels (their csum partial rows share one geometry; dK/dV needs 216 VGPRs = 2 waves per
+// SIMD), 12 for the forward (166 VGPRs = 3 per SIMD).  It matters where ONE workgroup fills the LDS (T = 577: 148 KiB of
+// K / V): 19 waves' worth of query tiles as 3 x 7 waves left a CU with 1.75 waves per SIMD in an issue-bound kernel; 2 x 10 is
+// 2.5 per SIMD and stages K / V twice per head instead of three times (r03).
+static void res_geometry(int T, int* nsplit, int* wpw, int max_waves = 8) {
   const int nq = cdiv(T, 16), nw = cdiv(nq, RES_RQ);
-  *nsplit = std::max(1, std::min(std::max(g_attn_split, cdiv(nw, 8)), nw));  // at most 8 waves per workgroup
+  *nsplit = std::max(1, std::min(std::max(g_attn_split, cdiv(nw, max_waves)), nw));
   *wpw = cdiv(nw, *nsplit);
   *nsplit = cdiv(nw, *wpw);
 }
 
 template <void (*FN)(AttnArgs)>
-static int launch_res(const AttnArgs& a, size_t smem, hipStream_t st) {
+static int launch_res(const AttnArgs& a, size_t smem, hipStream_t st, int max_waves = 8) {
   // dynamic LDS above 64 KiB needs the attribute; set it to the CU's 160 KiB once per KERNEL (the template parameter is the
   // kernel itself, not its type: all resident kernels share one function-pointer type)
   static bool done = false;
@@ -2388,7 +2390,7 @@ static int launch_res(const AttnArgs& a, size_t smem, hipStream_t st) {
   // with 4-wave workgroups three of them fit a CU (150 KiB of LDS, 12 of the 12 wave slots 152 VGPRs leave), so the
   // staging latency of one hides behind the key loops of the others; one 7-wave workgroup per CU paid it in the open.
   AttnArgs b = a;
-  res_geometry(a.T, &b.nsplit, &b.wpw);
+  res_geometry(a.T, &b.nsplit, &b.wpw, max_waves);
   hipLaunchKernelGGL(FN, dim3(a.B * a.H * b.nsplit), dim3(b.wpw * 64), smem, st, b);
   VIT_LAUNCH_CHECK();
   return VIT_OK;
@@ -2920,9 +2922,9 @@ int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo,
   a.drop = make_drop_h(h, dropout_p, seed, site);
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     const size_t img = 2 * (size_t)((T + 15) & ~15) * 2;  // K + V images: rows x dh_padded x 2 bytes each
-    if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream);
-    else if (a.dh <= 32) rc = launch_res<attn_fwd_res_kernel<32, RES_RQ, false>>(a, img * 32, (hipStream_t)stream);
-    else rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, false>>(a, img * 64, (hipStream_t)stream);
+    if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
+    else if (a.dh <= 32) rc = launch_res<attn_fwd_res_kernel<32, RES_RQ, false>>(a, img * 32, (hipStream_t)stream, g_attn_fwd_waves);
+    else rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, false>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);
