@@ -1932,15 +1932,21 @@ __device__ unsigned long long g_pipe_st[8 * 8];
 
 struct PipeHead { int bh, b, hh; };
 
+// HC: the head count when it is known at compile time (12: ViT-B -- row strides and head divisions become constants), else 0;
+// LOC: the context residual is present (the bf16 training path always passes it)
+template <bool FULL7, int HC, bool LOC>
 __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int DH = 64, TILE = RT * DH * 2, RQ = 2, ND = DH / 16;
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = p.T, BH = p.B * p.H;
-  const long ld = 3L * p.H * DH, ldc = (long)p.H * DH, HD = (long)p.H * DH;
-  const int R = (T + 15) & ~15, nq = R >> 4, np = (nq + 1) >> 1, nks = (T + 31) >> 5;
+  const int NH = HC ? HC : p.H;
+  const int T = p.T, BH = p.B * NH;
+  const long ld = 3L * NH * DH, ldc = (long)NH * DH, HD = (long)NH * DH;
+  // FULL7: 192 < T <= 208 -- every quantity derived from the padded length is a compile-time constant (LDS offsets become
+  // immediates, the key-step and tile loops lose their bounds tests)
+  const int R = FULL7 ? 208 : ((T + 15) & ~15), nq = R >> 4, np = (nq + 1) >> 1, nks = FULL7 ? 7 : ((T + 31) >> 5);
   char* ring = smem;
   const unsigned ring_a = lds_addr_of(smem);   // DMA destinations are raw LDS addresses
   char* lse_raw = ring + PIPE_NS * PIPE_SLOT;  // [slot][row group][64 words]: raw lse, word l = lse of row (l >> 3) of the group
@@ -1952,7 +1958,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   const int nheads = (BH - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const int G = nheads * np;  // pairs this workgroup walks
   const float c = p.scale * LOG2E;
-  const bool has_lo = p.ctx_lo != nullptr;
+  const bool has_lo = LOC || p.ctx_lo != nullptr;
   const float dscale = p.drop.thr ? p.drop.scale : 1.0f;  // 1 / (1 - p) of the kept probabilities
   // roles: waves 0-3 load dO / O / O_lo / lse of 8 rows each and derive their statistics (D); waves 4-7 load Q and run the
   // dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
@@ -1973,8 +1979,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   auto head_of = [&](int hidx) -> PipeHead {  // the integer division happens here, once per head and pipeline position
     PipeHead h;
     h.bh = (int)blockIdx.x + hidx * (int)gridDim.x;
-    h.b = h.bh / p.H;
-    h.hh = h.bh - h.b * p.H;
+    h.b = h.bh / NH;
+    h.hh = h.bh - h.b * NH;
     return h;
   };
   auto qoff_of = [&](const PipeHead& h) -> long { return (long)h.b * T * ld + (long)h.hh * DH; };
@@ -2067,7 +2073,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
           // stage was a chain of 7 LDS round trips (3 900 cycles per pair in the stamps, the critical path of the iteration).
           struct BFrag { bf16x8 ds, a, b; };
           auto bload = [&](int ks) -> BFrag {
-            const bool on = ks < nks, hi_ok = on && ks * 32 + 16 < R;
+            // FULL7 (192 < T <= 208, the ViT-B sequence): 7 key steps, the last one half full -- known at compile time, so the
+            // offsets are immediates and nothing is selected (70 of the stage's 118 VALU instructions were these adds / selects)
+            const bool on = FULL7 || ks < nks, hi_ok = FULL7 ? ks < 6 : (on && ks * 32 + 16 < R);
             const int od = on ? ks * 2048 : 0, okk = on ? ks * 4096 : 0, oh = hi_ok ? 1 : 0;
             bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + od));
             bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + od + oh * 1024));
@@ -3013,10 +3021,16 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
     if (g_attn_bwd_fused >= 4 && pipe_fits(T, dh)) {
       static bool attr = false;
       if (!attr) {
-        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
       }
-      hipLaunchKernelGGL(attn_bwd_pipe_kernel, dim3(std::min(B * H, ctx_num_cus(h))), dim3(512), pipe_smem(T), st, a);
+      const dim3 grid(std::min(B * H, ctx_num_cus(h)));
+      if (T > 192 && H == 12 && a.ctx_lo)  // the ViT-B shape: everything the padded length and the head count determine is constant
+        hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 12, true>), grid, dim3(512), pipe_smem(T), st, a);
+      else if (T > 192) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
+      else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
       VIT_LAUNCH_CHECK();
       return VIT_OK;
     }
