@@ -483,14 +483,18 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   // one half-tile = 2 LDS-DMA instructions per thread; destination: slot + round*8 KiB + wave*1 KiB (+ lane*16)
   static_assert(NSLOT == 8, "the ring arithmetic below is for 8 slots (two K-tiles of four half-tiles)");
   unsigned dofs = 0;  // byte offset of the slot the next stream index goes to (stream order: A0 B0 B1 A1 per K-tile)
+  // uniform 64-bit base + the thread's constant 32-bit byte offset, raw LDS address: three instructions per piece (a generic
+  // `char*` destination cost an aperture compare + null check per piece, the per-lane source a 64-bit VALU add; r03)
+  const unsigned smem_a = lds_addr_of(smem) + wave * 1024;
   auto issue_half = [&](const char* base, long half_off, const int (&off)[2]) {
-    char* dst = smem + dofs + wave * 1024;
+    const unsigned dst = smem_a + dofs;
     dofs = (dofs + HALF) & (NSLOT * HALF - 1);
 #ifdef VIT_PP_DIAG  // diagnostic build only (tools/pp_diag.py): 16 = no operand DMA, 32 = no fragment reads, 64 = no MFMAs, 128 = no epilogue
     if (p.debug & 16) return;
 #endif
-    lds_dma16(base + (half_off + off[0]) * 2, dst);
-    lds_dma16(base + (half_off + off[1]) * 2, dst + 8192);
+    const char* sb = base + half_off * 2;
+    lds_dma16_s(sb, (unsigned)off[0] * 2u, dst);
+    lds_dma16_s(sb, (unsigned)off[1] * 2u, dst + 8192);
   };
 
   // ---- fragment reads
@@ -859,11 +863,13 @@ __global__ __launch_bounds__(512, 2) void gemm3h_kernel(Gemm2Args p) {
   };
 
   unsigned dofs = 0;
+  const unsigned smem_a = lds_addr_of(smem) + wave * 1024;
   auto issue_half = [&](const char* base, long off_el, const int (&off)[2]) {
-    char* dst = smem + dofs + wave * 1024;
+    const unsigned dst = smem_a + dofs;
     dofs = (dofs + HALF) & (NSLOT * HALF - 1);
-    lds_dma16(base + (off_el + off[0]) * 2, dst);
-    lds_dma16(base + (off_el + off[1]) * 2, dst + 8192);
+    const char* sb = base + off_el * 2;
+    lds_dma16_s(sb, (unsigned)off[0] * 2u, dst);
+    lds_dma16_s(sb, (unsigned)off[1] * 2u, dst + 8192);
   };
 
   const int tq = l15 >> 2, tp = l15 & 3;
