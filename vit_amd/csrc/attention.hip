@@ -581,11 +581,13 @@ __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, i
                                            int lane, int nwaves = 8) {
   // image = nrows_img rows of 128 B, tile layout (row r at r * 128, chunk c at ((c ^ swz(r)) << 4))
   const int p = lane & 7;
+  const unsigned img_a = lds_addr_of(img);
   for (int j = wave; j < (nrows_img >> 3); j += nwaves) {
     const int r = (j << 3) + (lane >> 3);
     const int c = p ^ swz<64>(r & 63);
     const int grow = min(row0 + r, T - 1);
-    lds_dma16(g + (long)grow * ld + c * 8, img + j * 1024);
+    // uniform base + 32-bit lane offset (rows x row stride x 2 B stays far below 2^32 inside one head's rows), raw LDS address
+    lds_dma16_s(g, __umul24((unsigned)grow, (unsigned)(ld * 2)) + (unsigned)(c * 16), img_a + j * 1024);
   }
 }
 
@@ -1897,7 +1899,7 @@ __device__ __forceinline__ void dma_piece(char* dst, const short* g, long ld, in
   const int r = row_img + (lane >> 3), pc = lane & 7;
   const int c = SWZ ? (pc ^ swz<64>(r & 63)) : pc;
   const int grow = min(grow0 + r, T - 1);
-  lds_dma16(g + (long)grow * ld + c * 8, dst);
+  lds_dma16_s(g, __umul24((unsigned)grow, (unsigned)(ld * 2)) + (unsigned)(c * 16), lds_addr_of(dst));
 }
 // dS image of one pair: [key][32 queries] bf16, 64 B per key row, 8-byte slots (4 queries of one key) XOR-swizzled so that the
 // phase-A store (16 consecutive keys at one slot, banks mod 32) and the transposing read (8 consecutive keys x 4 adjacent
