@@ -183,7 +183,8 @@ def attn_ref(qkv, B, H, T, dh, scale, mask=None):
 ATT_SHAPES = [(2, 2, 129, 16), (2, 3, 5, 64), (2, 4, 197, 64), (1, 2, 300, 32), (1, 1, 70, 128), (1, 2, 64, 64), (1, 2, 90, 64),
               (1, 2, 120, 32), (1, 1, 577, 64),
               (1, 2, 1025, 16), (1, 1, 640, 64),  # these two: past the resident kernels
-              (1, 2, 4034, 16), (1, 1, 4034, 64)]  # the stride sweep's longest sequences (configs/sweep.yaml: S = 1 at L = 4096, P = 64)
+              (1, 2, 4034, 16), (1, 1, 4034, 64),  # the stride sweep's longest sequences (configs/sweep.yaml: S = 1 at L = 4096, P = 64)
+              (2, 12, 197, 64), (1, 12, 193, 64), (1, 12, 208, 64), (23, 12, 197, 64)]  # 12 heads, 192 < T <= 208: the compile-time forms
 
 
 @pytest.mark.parametrize("B,H,T,dh", ATT_SHAPES)
@@ -225,7 +226,7 @@ def extract_attn_mask(vf, dev, B, H, T, dh, drop):
     return mask
 
 
-@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (1, 3, 197, 64)])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (1, 3, 197, 64), (1, 12, 197, 64)])
 def test_attention_dropout(dev, B, H, T, dh):
     import vit_amd.functional as vf
 

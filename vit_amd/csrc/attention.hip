@@ -629,7 +629,7 @@ __device__ unsigned long long g_fwd_st[FWD_ST_WAVES * 8];
 
 // The key loop of one wave: RQ 16-row query tiles (fragments qf) against the staged K / V images of a head; running max m,
 // row sums l and the transposed output accumulators ot are the caller's.  pre_pv() runs once, before the first V fragment read.
-template <int DH, int RQ, class PrePV>
+template <int DH, int RQ, int TPC, class PrePV>  // TPC: 208 when 192 < T <= 208 is known at compile time (3 full tiles + one 16-key block), else 0
 __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, const bf16x8 (&qf)[RQ][DH / 32], float (&m)[RQ],
                                             float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int T, float c, const DropCfg& drop, int bh,
                                             int q00, int l15, int lg, PrePV&& pre_pv) {
@@ -725,6 +725,13 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
   using std::integral_constant;
   using no = integral_constant<bool, false>;
   using yes = integral_constant<bool, true>;
+  if constexpr (TPC == 208) {
+    tile(integral_constant<int, 4>{}, no{}, yes{}, 0);
+#pragma clang loop unroll(disable)  // unrolled, the scheduler overlaps the tiles and spills 50 registers per lane
+    for (int kt = 1; kt < 3; ++kt) tile(integral_constant<int, 4>{}, no{}, no{}, kt);
+    tile(integral_constant<int, 1>{}, yes{}, no{}, 3);
+    return;
+  }
   const int nfull = T / RT;
   // the first tile is peeled (the hook sits inside it); a sequence shorter than one full tile runs the hook before its only tile
   if (nfull > 0) tile(integral_constant<int, 4>{}, no{}, yes{}, 0);
@@ -741,17 +748,17 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
 }
 
 // Normalise, store the context rows (+ their rounding residual) and the row statistics of one wave's query tiles.
-template <int DH, int RQ, bool FULL = false>  // FULL: dh == DH is known at compile time (no row-per-lane store path compiled)
+template <int DH, int RQ, bool FULL = false, int HC = 0>  // FULL: dh == DH is known at compile time (no row-per-lane store path compiled); HC: head count, if known
 __device__ __forceinline__ void fwd_finish(const AttnArgs& p, const float (&m)[RQ], const float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int b,
                                            int h, int bh, int q00, float c, int l15, int lg) {
-  const int T = p.T, dh = p.dh;
+  const int T = p.T, dh = FULL ? DH : p.dh, NH = HC ? HC : p.H;
 #pragma unroll
   for (int rq = 0; rq < RQ; ++rq) {
     if (q00 + rq * 16 >= T) continue;  // uniform: a tile with no row below T has nothing to store
     const float lt = grp4_sum(l[rq]);
     const int q = q00 + rq * 16 + l15;
     const float inv = (p.drop.thr ? p.drop.scale : 1.0f) / lt;  // the kept probabilities' 1 / (1 - p) rides here
-    short* o = p.ctx + ((long)b * T + q) * (p.H * dh) + h * dh;
+    short* o = p.ctx + ((long)b * T + q) * (NH * dh) + h * dh;
     if ((FULL || dh == DH) && (DH % 32) == 0) {
       // 16-byte stores: two adjacent 16-column tiles per instruction (row-per-lane stores are issue-bound)
 #pragma unroll
@@ -784,7 +791,10 @@ __device__ __forceinline__ void fwd_finish(const AttnArgs& p, const float (&m)[R
 
 // DMA: dh == DH == 64 (compile-time, so that the untracked-load prologue below shares no control flow with tracked loads: the
 // compiler waits vmcnt(0) wherever a tracked load MIGHT be pending, and would drain the V image with it)
-template <int DH, int RQ, bool DMA>
+// TPC / HC: the ViT-B shape known at compile time (TPC = 208: 192 < T <= 208 launched as 2 workgroups x 4 waves per head;
+// HC = 12 heads): piece counts, waits, row strides and the tile sequence are constants (r03: the same specialisation took 7 %
+// off the pair-pipelined backward)
+template <int DH, int RQ, bool DMA, int TPC = 0, int HC = 0>
 __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
 #ifdef VIT_FWD_STAMP
@@ -798,18 +808,19 @@ __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
   // workgroups go to the XCDs round-robin (blockIdx % 8): deal each XCD a contiguous run of logical ids, so the nsplit
   // workgroups that stage the SAME head's K / V sit on one XCD, back to back, and the second one finds them in that L2
   const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int bh = wg / p.nsplit, part = wg - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
-  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
-  const long ld = 3L * p.H * dh;
+  const int NH = HC ? HC : p.H, NSPLIT = TPC ? 2 : p.nsplit, WPW = TPC ? 4 : p.wpw;
+  const int bh = wg / NSPLIT, part = wg - bh * NSPLIT, b = bh / NH, h = bh - b * NH;
+  const int T = p.T, dh = DMA ? DH : p.dh, ntl = (T + RT - 1) / RT;
+  const long ld = 3L * NH * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
-  const short* kb_ = qb + p.H * dh;
-  const short* vb = kb_ + p.H * dh;
+  const short* kb_ = qb + NH * dh;
+  const short* vb = kb_ + NH * dh;
   char* Kimg = smem;
   // only the 16-row blocks that hold keys are staged: 208 rows at T = 197 -> 52 KiB per workgroup, so THREE workgroups
   // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
-  const int rows_alloc = (T + 15) & ~15;
+  const int rows_alloc = TPC ? TPC : ((T + 15) & ~15);
   char* Vimg = smem + rows_alloc * (DH * 2);
-  const int q00 = (part * p.wpw + wave) * RQ * 16;
+  const int q00 = (part * WPW + wave) * RQ * 16;
   bf16x8 qf[RQ][DH / 32];
   float m[RQ], l[RQ];
   f32x4 ot[RQ][DH / 16];
@@ -837,7 +848,7 @@ __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
     // no registers, no zero-fill moves, no address arithmetic per chunk: this kernel saturates the VALU (PMC: 3 waves x 33 %
     // VALU-active per SIMD) and the register-staged form spent ~300 VALU instructions per wave here.  Keys past T are
     // masked to -inf in the edge tile, so the clamped duplicate rows are never used.
-    const int nwv = blockDim.x >> 6, npc = rows_alloc >> 3;
+    const int nwv = TPC ? 4 : (int)(blockDim.x >> 6), npc = rows_alloc >> 3;
     dma_rows64(Kimg, kb_, ld, 0, rows_alloc, T, wave, lane, nwv);
     dma_rows64(Vimg, vb, ld, 0, rows_alloc, T, wave, lane, nwv);
     wait_vmcnt_dyn(wave < npc ? (npc - wave + nwv - 1) / nwv : 0);  // all but this wave's V pieces: Q and K are in
@@ -874,14 +885,14 @@ __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
 #endif
   FWD_ST(2)  // Q fragments in registers
 
-  fwd_keyloop<DH, RQ>(Kimg, Vimg, qf, m, l, ot, T, c, p.drop, bh, q00, l15, lg, [&]() {
+  fwd_keyloop<DH, RQ, TPC>(Kimg, Vimg, qf, m, l, ot, T, c, p.drop, bh, q00, l15, lg, [&]() {
     if (v_pending) {  // V in and published before its first fragment read
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   });
   FWD_ST(3)  // key loop
-  fwd_finish<DH, RQ, DMA>(p, m, l, ot, b, h, bh, q00, c, l15, lg);
+  fwd_finish<DH, RQ, DMA, HC>(p, m, l, ot, b, h, bh, q00, c, l15, lg);
 #ifdef VIT_FWD_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FWD_ST(4)  // normalise + stores retired
@@ -2932,7 +2943,11 @@ int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo,
   a.drop = make_drop_h(h, dropout_p, seed, site);
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
     const size_t img = 2 * (size_t)((T + 15) & ~15) * 2;  // K + V images: rows x dh_padded x 2 bytes each
-    if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
+    int ns_ = 0, wp_ = 0;
+    res_geometry(T, &ns_, &wp_, g_attn_fwd_waves);
+    if (a.dh == 64 && T > 192 && T <= 208 && H == 12 && ns_ == 2 && wp_ == 4)
+      rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true, 208, 12>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
+    else if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
     else if (a.dh <= 32) rc = launch_res<attn_fwd_res_kernel<32, RES_RQ, false>>(a, img * 32, (hipStream_t)stream, g_attn_fwd_waves);
     else rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, false>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
     return rc;
