@@ -184,7 +184,8 @@ ATT_SHAPES = [(2, 2, 129, 16), (2, 3, 5, 64), (2, 4, 197, 64), (1, 2, 300, 32), 
               (1, 2, 120, 32), (1, 1, 577, 64),
               (1, 2, 1025, 16), (1, 1, 640, 64),  # these two: past the resident kernels
               (1, 2, 4034, 16), (1, 1, 4034, 64),  # the stride sweep's longest sequences (configs/sweep.yaml: S = 1 at L = 4096, P = 64)
-              (2, 12, 197, 64), (1, 12, 193, 64), (1, 12, 208, 64), (23, 12, 197, 64)]  # 12 heads, 192 < T <= 208: the compile-time forms
+              (2, 12, 197, 64), (1, 12, 193, 64), (1, 12, 208, 64), (23, 12, 197, 64),  # 12 heads, 192 < T <= 208: the compile-time forms
+              (1, 16, 577, 64), (2, 16, 592, 64)]  # the ViT-L head count and sequence
 
 
 @pytest.mark.parametrize("B,H,T,dh", ATT_SHAPES)

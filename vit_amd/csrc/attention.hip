@@ -629,7 +629,7 @@ __device__ unsigned long long g_fwd_st[FWD_ST_WAVES * 8];
 
 // The key loop of one wave: RQ 16-row query tiles (fragments qf) against the staged K / V images of a head; running max m,
 // row sums l and the transposed output accumulators ot are the caller's.  pre_pv() runs once, before the first V fragment read.
-template <int DH, int RQ, int TPC, class PrePV>  // TPC: 208 when 192 < T <= 208 is known at compile time (3 full tiles + one 16-key block), else 0
+template <int DH, int RQ, int TPC, class PrePV>  // TPC: the padded length 64 n + 16 when TPC - 16 < T <= TPC is known at compile time (208: ViT-B, 592: ViT-L), else 0
 __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, const bf16x8 (&qf)[RQ][DH / 32], float (&m)[RQ],
                                             float (&l)[RQ], f32x4 (&ot)[RQ][DH / 16], int T, float c, const DropCfg& drop, int bh,
                                             int q00, int l15, int lg, PrePV&& pre_pv) {
@@ -725,11 +725,13 @@ __device__ __forceinline__ void fwd_keyloop(const char* Kimg, const char* Vimg, 
   using std::integral_constant;
   using no = integral_constant<bool, false>;
   using yes = integral_constant<bool, true>;
-  if constexpr (TPC == 208) {
+  if constexpr (TPC != 0) {  // TPC = 64 n + 16: n full tiles and one 16-key block
+    static_assert(TPC % 64 == 16, "compile-time sequence lengths end in one 16-key block");
+    constexpr int NFULL = TPC / 64;
     tile(integral_constant<int, 4>{}, no{}, yes{}, 0);
 #pragma clang loop unroll(disable)  // unrolled, the scheduler overlaps the tiles and spills 50 registers per lane
-    for (int kt = 1; kt < 3; ++kt) tile(integral_constant<int, 4>{}, no{}, no{}, kt);
-    tile(integral_constant<int, 1>{}, yes{}, no{}, 3);
+    for (int kt = 1; kt < NFULL; ++kt) tile(integral_constant<int, 4>{}, no{}, no{}, kt);
+    tile(integral_constant<int, 1>{}, yes{}, no{}, NFULL);
     return;
   }
   const int nfull = T / RT;
@@ -791,10 +793,11 @@ __device__ __forceinline__ void fwd_finish(const AttnArgs& p, const float (&m)[R
 
 // DMA: dh == DH == 64 (compile-time, so that the untracked-load prologue below shares no control flow with tracked loads: the
 // compiler waits vmcnt(0) wherever a tracked load MIGHT be pending, and would drain the V image with it)
-// TPC / HC: the ViT-B shape known at compile time (TPC = 208: 192 < T <= 208 launched as 2 workgroups x 4 waves per head;
-// HC = 12 heads): piece counts, waits, row strides and the tile sequence are constants (r03: the same specialisation took 7 %
+// TPC / HC / NSP / WPWC: a shape known at compile time (TPC = 208: 192 < T <= 208, 12 heads, 2 workgroups x 4 waves per head:
+// ViT-B): piece counts, waits, row strides and the tile sequence are constants.  (The same for ViT-L -- 592, 16 heads, 2 x 10
+// waves -- measured no gain: its nine-tile key loop dominates and is the same code.) (r03: the same specialisation took 7 %
 // off the pair-pipelined backward)
-template <int DH, int RQ, bool DMA, int TPC = 0, int HC = 0>
+template <int DH, int RQ, bool DMA, int TPC = 0, int HC = 0, int NSP = 0, int WPWC = 0>
 __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
 #ifdef VIT_FWD_STAMP
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
   // workgroups go to the XCDs round-robin (blockIdx % 8): deal each XCD a contiguous run of logical ids, so the nsplit
   // workgroups that stage the SAME head's K / V sit on one XCD, back to back, and the second one finds them in that L2
   const int wg = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int NH = HC ? HC : p.H, NSPLIT = TPC ? 2 : p.nsplit, WPW = TPC ? 4 : p.wpw;
+  const int NH = HC ? HC : p.H, NSPLIT = TPC ? NSP : p.nsplit, WPW = TPC ? WPWC : p.wpw;
   const int bh = wg / NSPLIT, part = wg - bh * NSPLIT, b = bh / NH, h = bh - b * NH;
   const int T = p.T, dh = DMA ? DH : p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * NH * dh;
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(768, 3) void attn_fwd_res_kernel(AttnArgs p) {
     // no registers, no zero-fill moves, no address arithmetic per chunk: this kernel saturates the VALU (PMC: 3 waves x 33 %
     // VALU-active per SIMD) and the register-staged form spent ~300 VALU instructions per wave here.  Keys past T are
     // masked to -inf in the edge tile, so the clamped duplicate rows are never used.
-    const int nwv = TPC ? 4 : (int)(blockDim.x >> 6), npc = rows_alloc >> 3;
+    const int nwv = TPC ? WPWC : (int)(blockDim.x >> 6), npc = rows_alloc >> 3;
     dma_rows64(Kimg, kb_, ld, 0, rows_alloc, T, wave, lane, nwv);
     dma_rows64(Vimg, vb, ld, 0, rows_alloc, T, wave, lane, nwv);
     wait_vmcnt_dyn(wave < npc ? (npc - wave + nwv - 1) / nwv : 0);  // all but this wave's V pieces: Q and K are in
@@ -2946,7 +2949,7 @@ int vit_attention_fwd_lo(vit_handle h, const void* qkv, void* ctx, void* ctx_lo,
     int ns_ = 0, wp_ = 0;
     res_geometry(T, &ns_, &wp_, g_attn_fwd_waves);
     if (a.dh == 64 && T > 192 && T <= 208 && H == 12 && ns_ == 2 && wp_ == 4)
-      rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true, 208, 12>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
+      rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true, 208, 12, 2, 4>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
     else if (a.dh == 64) rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, true>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
     else if (a.dh <= 32) rc = launch_res<attn_fwd_res_kernel<32, RES_RQ, false>>(a, img * 32, (hipStream_t)stream, g_attn_fwd_waves);
     else rc = launch_res<attn_fwd_res_kernel<64, RES_RQ, false>>(a, img * 64, (hipStream_t)stream, g_attn_fwd_waves);
