@@ -598,3 +598,44 @@ def test_attention_forward_hooks_receive_maps(dev):
     seen.clear()
     model(x, labels=labels)
     assert not seen
+
+
+@pytest.mark.parametrize("precision,tol", [("32", 1e-2), ("bf16-mixed", 1.5e-1)])
+def test_long_trajectory_tracks_the_oracle(dev, precision, tol):
+    """120 optimisation steps (fwd -> bwd -> clip 0.5 -> AdamW 1e-3, dropout off) at C1 over 24 batches, the HIP path against
+    the CPU oracle stepping from the same weights on the same batches: the loss curves must stay together for the whole run,
+    not only for the three steps the fixtures hold.  Adam turns rounding differences into +-lr element steps, so the gate is
+    on the curve, not on the weights: |loss - oracle loss| relative to the oracle's loss (floored at 5 % of the initial
+    loss), worst step, for precision '32' (measured on MI355X: worst 1.7e-3, mean 1.8e-4, epoch means equal to 2e-4); for
+    bf16-mixed the per-step losses of this small, noisy fit scatter (a 32-wide model on random labels), so the gate is on
+    the five epoch means (measured: within 11 %; both curves fall 0.184 -> 0.09)."""
+    from oracle import refvit
+    from vit_amd.optimizer import FusedAdamW
+
+    rc, g, sd, model, _, _ = setup("c1", dev, precision=precision)
+    model.eval()  # dropout off on both sides; the engine still trains (the optimizer steps)
+    gen = torch.Generator().manual_seed(77)
+    batches = [(torch.randn(16, rc.image_size, generator=gen), torch.rand(16, generator=gen)) for _ in range(24)]
+    ref = refvit.RefTrainer(rc, sd, lr=1e-3, training=False)
+    opt = FusedAdamW(model, lr=1e-3)
+    opt.set_grad_clip(0.5)
+    worst, ours, theirs = 0.0, [], []
+    for i in range(120):
+        x, y = batches[i % 24]
+        lr_ = ref.step(x, y)
+        opt.zero_grad()
+        loss = model(x.to(dev), labels=y.to(dev)).loss
+        loss.backward()
+        opt.step()
+        ours.append(float(loss))
+        theirs.append(lr_)
+    floor = 0.05 * theirs[0]
+    dev_ = [abs(a - b) / max(b, floor) for a, b in zip(ours, theirs)]
+    ep_o = [float(np.mean(ours[e * 24:(e + 1) * 24])) for e in range(5)]
+    ep_t = [float(np.mean(theirs[e * 24:(e + 1) * 24])) for e in range(5)]
+    ep_dev = max(abs(a - b) / b for a, b in zip(ep_o, ep_t))
+    print(f"[{precision}] 120 steps, epoch means oracle {[round(v, 4) for v in ep_t]} HIP {[round(v, 4) for v in ep_o]}: worst epoch "
+          f"deviation {ep_dev:.2e}; per step: worst {max(dev_):.2e} at step {int(np.argmax(dev_))}, mean {np.mean(dev_):.2e}")
+    assert ep_t[-1] < 0.5 * theirs[0]  # the run actually trains
+    worst = max(dev_) if precision == "32" else ep_dev  # bf16: per-step losses of a noisy fit scatter; the epoch means are the curve
+    assert worst < tol, (worst, ours[-5:], theirs[-5:])
