@@ -162,7 +162,19 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
   const int c = blockIdx.x * 64 + tx;
   float a0 = 0.f, a1 = 0.f;
   if (c < width) {
+    // 8 rows per pass, all 8 loads issued before the first add: with two loads per pass the 512-row reductions of a step were
+    // a chain of 16 L2 round trips (6.7 us per launch, ~50 launches per step; r03).  Fixed summation order per (ty, column).
     int k = ty;
+    for (; k + 7 * 16 < nblk; k += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u * 16) * stride + c];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        a0 += v[u];
+        a1 += v[u + 1];
+      }
+    }
     for (; k + 16 < nblk; k += 32) {
       a0 += part[(long)k * stride + c];
       a1 += part[(long)(k + 16) * stride + c];
@@ -191,8 +203,17 @@ __global__ __launch_bounds__(1024) void reduce_partials_stage1_kernel(float* __r
   const int c = blockIdx.x * 64 + tx;
   const int r0 = blockIdx.y * chunk, r1 = min(nblk, r0 + chunk);
   float a = 0.f;
-  if (c < width)
-    for (int k = r0 + ty; k < r1; k += 16) a += part[(long)k * stride + c];
+  if (c < width) {
+    int k = r0 + ty;
+    for (; k + 3 * 16 < r1; k += 4 * 16) {  // four loads in flight, added in row order
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = part[(long)(k + u * 16) * stride + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a += v[u];
+    }
+    for (; k < r1; k += 16) a += part[(long)k * stride + c];
+  }
   red[ty][tx] = a;
   __syncthreads();
   if (ty == 0 && c < width) {
