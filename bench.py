@@ -136,6 +136,9 @@ def main():
                          "Measured equal to eager launches within noise (the host runs ahead of the GPU either way) and 0.7 ms "
                          "slower when combined with the second stream, so it is opt-in and switches the second stream off")
     ap.add_argument("--no-graph", action="store_true", help="(default now; kept so older command lines still parse)")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="size the one-workgroup-per-CU kernels for this many fewer CUs (room for the collective's kernels when "
+                         "the gradient exchange overlaps the backward; 0 = all CUs)")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
     ap.add_argument("--launch-check", action="store_true",
                     help="rank plumbing only (no GPU): every rank joins a gloo group, rank 0 prints {world, sum of ranks}")
@@ -184,6 +187,8 @@ def main():
         "data": {"param": "log_g"},
         "noise": {"noise_level": 0},
     }
+    if args.reserve_cus:
+        _cabi.set_option("reserve_cus", args.reserve_cus)
     seed_everything(42)  # scripts/run.py:22,28
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
@@ -361,7 +366,7 @@ def main():
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
                        "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
-                       "final_loss": final_loss,
+                       "final_loss": final_loss, "reserve_cus": args.reserve_cus,
                        "launch": "one hipGraph replay per step" if use_graph else
                        ("eager launches, weight-gradient GEMMs on a second HIP stream" if module.model.engine.overlap_dw
                         else "eager launches, one stream")},

@@ -63,6 +63,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "gemm_half_tail": 1 (default) = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
  *                and plain dX epilogues; 2 = the GELU epilogue too) run in a second launch as half tiles, two workgroups per
  *                tile; 0 = one launch.
+ *   "reserve_cus": 0 (default) .. 128 = the one-workgroup-per-CU kernels (ping-pong GEMMs, pair-pipelined attention backward) size
+ *                their grids for that many fewer CUs, leaving room for a collective's kernels that overlap them (data-parallel
+ *                runs; bench.py --reserve-cus).
  *   "attn_fwd_waves": 12 (default) or 8 = most waves per workgroup of the resident attention forward; only changes the launch
  *                where one workgroup fills the LDS (head_dim 64, T > ~290): 577 tokens run as 2 x 10 waves instead of 3 x 7.
  *   "gemm_split_tail": 1 (default) = a SHORT tail (at most a quarter of the workgroup slots) of a long-K product runs as K-slices of

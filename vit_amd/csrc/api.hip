@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 struct vit_ctx {
@@ -30,10 +32,16 @@ void set_error(const char* fmt, ...) {
 
 const StepState* ctx_step_state(vit_handle h) { return h ? (const StepState*)h->step_state : nullptr; }
 
+// vit_set_option("reserve_cus", n): the persistent kernels (one workgroup per CU: ping-pong GEMMs, pair-pipelined attention
+// backward) size their grids for n fewer CUs.  For data-parallel runs: an RCCL kernel that overlaps the backward needs CUs of
+// its own (a 512-thread GEMM workgroup owns its CU's whole register file), and a persistent grid that does not fit runs its
+// last workgroups as a second round -- twice the kernel time instead of n / 256 more.  Default 0; to be tuned on a measured
+// scaling curve.
+int g_reserve_cus = 0;
 int ctx_num_cus(vit_handle h) {
   // without a handle (kernel-level calls of the C ABI that pass NULL): the current device, asked once
   static int dflt = 0;
-  if (h) return h->num_cus;
+  if (h) return std::max(1, h->num_cus - g_reserve_cus);
   if (!dflt) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -41,7 +49,7 @@ int ctx_num_cus(vit_handle h) {
     else
       dflt = 256;
   }
-  return dflt;
+  return std::max(1, dflt - g_reserve_cus);
 }
 
 void* ctx_workspace(vit_handle h, size_t* bytes) {
@@ -103,6 +111,14 @@ int vit_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_bwd_fused") == 0) {
     vit::g_attn_bwd_fused = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "reserve_cus") == 0) {
+    if (value < 0 || value > 128) {
+      vit::set_error("vit_set_option: reserve_cus takes 0 .. 128");
+      return VIT_ERR_ARG;
+    }
+    vit::g_reserve_cus = value;
     return VIT_OK;
   }
   if (strcmp(name, "attn_fwd_waves") == 0) {
