@@ -50,3 +50,47 @@ def test_error_path_without_gpu():
     assert b"null operand" in lib.vit_last_error()
     rc = lib.vit_layernorm_fwd(None, None, None, None, None, 1, None, None, 4, 32, 1e-12, None)
     assert rc == -1
+
+
+def test_untracked_q_loads_are_not_read_before_their_wait(tmp_path):
+    """The resident attention forward requests its Q rows with inline-asm loads the compiler does not track (so that it
+    does not drain the K / V LDS-DMA with them); the counted s_waitcnt that covers them is hand-placed.  Nothing may read
+    or move those destination registers between the loads and that wait -- checked here on the ISA hipcc emits for both
+    forms of the kernel (a compiler that copied the registers early would produce garbage only the GPU tests could see)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit_amd", "csrc", "attention.hip")
+    out = tmp_path / "attention.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
+                   check=True, capture_output=True, cwd=str(tmp_path))
+    text = out.read_text()
+
+    def regs(line):
+        r = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+            r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            r.add(int(m.group(1)))
+        return r
+
+    kernels = re.findall(r"^(_ZN3vit19attn_fwd_res_kernelILi64ELi2ELb1E\w+):", text, flags=re.M)
+    assert len(kernels) >= 2, kernels  # the generic DMA form and the compile-time ViT-B form
+    for name in kernels:
+        a = text.index(name + ":")
+        body = [l.strip() for l in text[a:text.index("s_endpgm", a)].split("\n")]
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx4") and body[i - 1].startswith(";;#ASMSTART")]
+        assert len(loads) == 4, (name, len(loads))
+        dst = set()
+        for i in loads:
+            dst |= regs(body[i].split(",")[0])
+        wait = next(i for i, l in enumerate(body) if i > loads[-1] and "s_waitcnt vmcnt" in l)
+        for i in range(loads[-1] + 1, wait):
+            l = body[i]
+            if not l or l.startswith(";") or l.startswith(".") or "global_load_lds" in l:
+                continue
+            assert not (regs(l) & dst), (name, i, l)
