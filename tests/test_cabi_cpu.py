@@ -52,23 +52,62 @@ def test_error_path_without_gpu():
     assert rc == -1
 
 
-def test_untracked_q_loads_are_not_read_before_their_wait(tmp_path):
-    """The resident attention forward requests its Q rows with inline-asm loads the compiler does not track (so that it
-    does not drain the K / V LDS-DMA with them); the counted s_waitcnt that covers them is hand-placed.  Nothing may read
-    or move those destination registers between the loads and that wait -- checked here on the ISA hipcc emits for both
-    forms of the kernel (a compiler that copied the registers early would produce garbage only the GPU tests could see)."""
-    import re
+@pytest.fixture(scope="module")
+def kernel_isa(tmp_path_factory):
+    """ISA text of attention.hip and gemm2.hip as hipcc emits it for gfx950 (cross-compiled: no GPU needed)."""
     import shutil
     import subprocess
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit_amd", "csrc", "attention.hip")
-    out = tmp_path / "attention.s"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", str(out)],
-                   check=True, capture_output=True, cwd=str(tmp_path))
-    text = out.read_text()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vit_amd", "csrc")
+    d = tmp_path_factory.mktemp("isa")
+    out = {}
+    for f in ("attention", "gemm2"):
+        o = d / (f + ".s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(root, f + ".hip"),
+                        "-o", str(o)], check=True, capture_output=True, cwd=str(d))
+        out[f] = o.read_text()
+    return out
+
+
+def _kernel_bodies(text, pattern):
+    import re
+    for name in re.findall(r"^(" + pattern + r"):", text, flags=re.M):
+        a = text.index(name + ":")
+        yield name, [l.strip() for l in text[a:text.index("s_endpgm", a)].split("\n")]
+
+
+def test_no_drain_inside_the_dma_pipelines(kernel_isa):
+    """r03's largest finding, pinned: no `s_waitcnt vmcnt(0)` and no scratch access may sit inside the loops that keep LDS-DMA in
+    flight -- the K loop of every ping-pong GEMM instantiation (between its first and last MFMA) and the pair loop of the
+    pair-pipelined attention backward (whose only vmcnt(0) is case 0 of its counted wait).  The compiler wrote such waits
+    itself when the DMA went through its builtin, and writes one for every scratch reload."""
+    n = 0
+    for name, body in _kernel_bodies(kernel_isa["gemm2"], r"_ZN3vit12gemm3_kernelI\w+"):
+        mf = [i for i, l in enumerate(body) if l.startswith("v_mfma")]
+        loop = body[mf[0]:mf[-1] + 1]
+        assert not [l for l in loop if "vmcnt(0)" in l], name
+        assert not [l for l in loop if "scratch_" in l], name
+        n += 1
+    assert n >= 8, n
+    m = 0
+    for name, body in _kernel_bodies(kernel_isa["attention"], r"_ZN3vit20attn_bwd_pipe_kernelI\w+"):
+        assert sum("vmcnt(0)" in l for l in body) <= 1, name
+        assert not [l for l in body if "scratch_" in l], name
+        m += 1
+    assert m >= 2, m
+
+
+def test_untracked_q_loads_are_not_read_before_their_wait(kernel_isa):
+    """The resident attention forward requests its Q rows with inline-asm loads the compiler does not track (so that it
+    does not drain the K / V LDS-DMA with them); the counted s_waitcnt that covers them is hand-placed.  Nothing may read
+    or move those destination registers between the loads and that wait -- checked here on the ISA hipcc emits for both
+    forms of the kernel (a compiler that copied the registers early would produce garbage only the GPU tests could see)."""
+    import re
+
+    text = kernel_isa["attention"]
 
     def regs(line):
         r = set()
@@ -78,11 +117,9 @@ def test_untracked_q_loads_are_not_read_before_their_wait(tmp_path):
             r.add(int(m.group(1)))
         return r
 
-    kernels = re.findall(r"^(_ZN3vit19attn_fwd_res_kernelILi64ELi2ELb1E\w+):", text, flags=re.M)
-    assert len(kernels) >= 2, kernels  # the generic DMA form and the compile-time ViT-B form
-    for name in kernels:
-        a = text.index(name + ":")
-        body = [l.strip() for l in text[a:text.index("s_endpgm", a)].split("\n")]
+    kernels = list(_kernel_bodies(text, r"_ZN3vit19attn_fwd_res_kernelILi64ELi2ELb1E\w+"))
+    assert len(kernels) >= 2, [k for k, _ in kernels]  # the generic DMA form and the compile-time ViT-B form
+    for name, body in kernels:
         loads = [i for i, l in enumerate(body) if l.startswith("global_load_dwordx4") and body[i - 1].startswith(";;#ASMSTART")]
         assert len(loads) == 4, (name, len(loads))
         dst = set()
