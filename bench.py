@@ -47,10 +47,6 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def ms_per_step_of(dt, steps):
-    return dt / steps * 1e3
-
-
 def train_flop_per_image(L, P, D, layers, F):
     """2*3*[N*P*D + layers*(3TD^2 + 2T^2 D + TD^2 + 2TDF) + D^2 + D]."""
     N = L // P
@@ -80,24 +76,50 @@ def launch_check(n_expected: int):
         raise SystemExit(f"--gpus {n_expected} but WORLD_SIZE={world}")
 
 
-def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, dt):
-    """N > 1: the same steps with the exchange switched off, and the bare all-reduce of the step's buckets."""
+def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, median_ms):
+    """N > 1 (or the single-rank rehearsal), after `value` is taken: what the gradient exchange costs and which of the
+    N > 1 knobs pays, from ONE invocation (no scaling curve was ever measured for this path, so the first multi-GPU run has to
+    answer these by itself).  Every figure is the median per-step hipEvent time of `probe_steps` steps, MAX over ranks:
+      * the step with the exchange switched off (replicas drift apart, which no longer matters) -> exposed exchange time;
+      * the bare all-reduce of the step's buckets with nothing else on the GPU -> algorithm / bus bandwidth over xGMI;
+      * `reserve_cus` in {0, 8, 16, 32}: the ping-pong GEMMs and the pair-pipelined attention backward are persistent grids of
+        one workgroup per CU, so an overlapping RCCL kernel has no CU to run on unless some are left free -- step time with
+        and without the exchange at each setting;
+      * the `zero1` schedule (reduce-scatter, sharded AdamW, parameter all-gather) at reserve 0 and at the best reserve;
+      * strong scaling: a fixed global batch of 256 images (256 / N per GPU), SURVEY.md section 8d."""
     import torch
 
+    from vit_amd import _cabi
+    from vit_amd import ddp as ddp_mod
+
     dist = torch.distributed
-    n_probe = min(args.steps, 10)
-    trainer.reducer, eng.grad_ready_cb = None, None
-    if hasattr(trainer.optimizer, "attach_reducer"):
-        trainer.optimizer.attach_reducer(None)
-    barrier()
-    t2 = time.perf_counter()
-    for i in range(n_probe):
-        trainer.training_step(module, batch, i)
-    barrier()
-    dt_off = time.perf_counter() - t2
-    trainer.reducer, eng.grad_ready_cb = red, red.bucket_ready
-    if hasattr(trainer.optimizer, "attach_reducer"):
-        trainer.optimizer.attach_reducer(red)
+    n_probe = max(2, min(args.steps, 10))
+
+    def run(n, b=batch):
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            trainer.training_step(module, b, i)
+            ev[i + 1].record()
+        barrier()
+        t = torch.tensor([ev[i].elapsed_time(ev[i + 1]) for i in range(n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.median())
+
+    def set_exchange(r):
+        trainer.reducer = r
+        eng.grad_ready_cb = r.bucket_ready if r is not None else None
+        if hasattr(trainer.optimizer, "attach_reducer"):
+            trainer.optimizer.attach_reducer(r)
+
+    out = {"probe_steps": n_probe}
+    set_exchange(None)
+    off0 = run(n_probe)
+    set_exchange(red)
+    out["ms_per_step_exchange_off"] = round(off0, 3)
+    out["exposed_exchange_ms"] = round(median_ms - off0, 3)
+    # the bare collective
     barrier()
     t3 = time.perf_counter()
     for _ in range(n_probe):
@@ -105,15 +127,53 @@ def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, dt):
             red.bucket_ready(lo, hi)
         red.finish()
     barrier()
-    dt_ar = time.perf_counter() - t3
-    t = torch.tensor([dt_off, dt_ar], dtype=torch.float64, device=dev)
+    t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_off, dt_ar = float(t[0]), float(t[1])
+    dt_ar = float(t[0])
     alg = red.bytes_per_step / (dt_ar / n_probe) / 1e9
-    return {"ms_per_step_exchange_off": round(dt_off / n_probe * 1e3, 3),
-            "exposed_exchange_ms": round(ms_per_step_of(dt, args.steps) - dt_off / n_probe * 1e3, 3),
-            "bare_allreduce_ms": round(dt_ar / n_probe * 1e3, 3), "algbw_GBps": round(alg, 1),
-            "busbw_GBps": round(alg * 2 * (world - 1) / world, 1), "probe_steps": n_probe}
+    out.update({"bare_allreduce_ms": round(dt_ar / n_probe * 1e3, 3), "algbw_GBps": round(alg, 1),
+                "busbw_GBps": round(alg * 2 * (world - 1) / world, 1)})
+    # reserve_cus sweep, all-reduce schedule
+    sweep, best = [], (median_ms, args.reserve_cus)
+    for rc in (0, 8, 16, 32):
+        _cabi.set_option("reserve_cus", rc)
+        on = run(n_probe)
+        set_exchange(None)
+        off = run(n_probe)
+        set_exchange(red)
+        sweep.append({"reserve_cus": rc, "ms_per_step": round(on, 3), "ms_per_step_exchange_off": round(off, 3),
+                      "exposed_exchange_ms": round(on - off, 3)})
+        if on < best[0]:
+            best = (on, rc)
+    off_by_rc = {x["reserve_cus"]: x["ms_per_step_exchange_off"] for x in sweep}
+    out["reserve_cus_sweep"] = sweep
+    out["best_reserve_cus"] = best[1]
+    # the sharded schedule
+    try:
+        z = ddp_mod.make_reducer("zero1", eng, grad_dtype="fp32", max_bucket_elems=getattr(trainer, "max_bucket_elems", 64 << 20))
+        zs = []
+        for rc in sorted({0, best[1]}):
+            _cabi.set_option("reserve_cus", rc)
+            set_exchange(z)
+            on = run(n_probe)
+            zs.append({"reserve_cus": rc, "ms_per_step": round(on, 3),
+                       "exposed_exchange_ms": round(on - off_by_rc.get(rc, off0), 3)})
+        out["zero1"] = zs
+    except Exception as e:  # noqa: BLE001
+        out["zero1_error"] = f"{type(e).__name__}: {e}"
+    set_exchange(red)
+    _cabi.set_option("reserve_cus", args.reserve_cus)
+    # strong scaling at a global batch of 256
+    B = batch[0].shape[0]
+    if not args.global_batch and 256 % world == 0 and 256 // world != B and 256 // world <= B:
+        bs = 256 // world
+        small = tuple(t[:bs].contiguous() for t in batch)
+        for i in range(2):
+            trainer.training_step(module, small, i)  # the arena of the new batch size
+        ms = run(n_probe, small)
+        out["strong_scaling"] = {"global_batch": 256, "per_gpu_batch": bs, "ms_per_step": round(ms, 3),
+                                 "images_per_s": round(256 / (ms * 1e-3), 2)}
+    return out
 
 
 def main():
@@ -139,6 +199,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=0,
                     help="size the one-workgroup-per-CU kernels for this many fewer CUs (room for the collective's kernels when "
                          "the gradient exchange overlaps the backward; 0 = all CUs)")
+    ap.add_argument("--no-gc-freeze", action="store_true",
+                    help="diagnostic: leave the start-up heap in the cyclic GC's young generations (shows the pause the freeze removes)")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
     ap.add_argument("--launch-check", action="store_true",
                     help="rank plumbing only (no GPU): every rank joins a gloo group, rank 0 prints {world, sum of ranks}")
@@ -247,12 +309,47 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         log(f"timing {args.steps} steps")
+    # BASELINE.md section 2 / SURVEY.md section 8d: per-step hipEvent times, median.  One event record per step boundary on the
+    # launch stream (the step ends on it: the optimizer kernels wait for the side stream and the collective) -- K + 1 records
+    # in all, nothing else inside the region.  `value` is taken from the MEDIAN step; the region mean (wall clock between the
+    # two barriers, the contract's bracket) is reported beside it as `mean_ms_per_step`.
+    # Host-side transients are made visible instead of guessed at: `host_ms` = wall time the host spent ISSUING each step
+    # (no sync inside), and every garbage collection that runs inside the region is recorded with its duration.  What r03's
+    # driver line showed (region mean 36.8 ms against 35.0 for every step but one) was ONE such pause: a generation-2
+    # collection of CPython's cyclic GC landing in a timed step (every step allocates a few thousand tracked objects; with the
+    # ~10^6 objects that importing torch leaves on the heap a full collection takes 50-100 ms, during which nothing is
+    # launched and the GPU drains).  The trainer's step loop runs with the start-up heap frozen (Trainer.freeze_heap(): one
+    # collect, then gc.freeze(), so later collections scan only what the steps allocate); the bench does the same after warm-up.
+    import gc
+
+    if not args.no_gc_freeze:
+        trainer.freeze_heap()
+    gc_events, gc_t = [], [0.0]
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_t[0] = time.perf_counter()
+        else:
+            gc_events.append({"generation": info["generation"], "ms": round((time.perf_counter() - gc_t[0]) * 1e3, 3),
+                              "at_step": len(host_ms)})
+
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms = []
+    gc.callbacks.append(gc_cb)
     t0 = time.perf_counter()
+    marks[0].record()
+    th = t0
     for i in range(args.steps):
         loss = trainer.training_step(module, batch, i)
+        marks[i + 1].record()
+        tn = time.perf_counter()
+        host_ms.append((tn - th) * 1e3)
+        th = tn
     barrier()
     dt = time.perf_counter() - t0
+    gc.callbacks.remove(gc_cb)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     # The per-GEMM HIP-event brackets (two event records around each of ~170 vit_gemm calls per step) cost 2-4 % of a
     # step, so `value` comes from the clean region above and the kernel-level roofline from an instrumented repetition
     # of the same steps right after it (same state, same inputs; `roofline.instrumented_ms_per_step` says what they took).
@@ -273,11 +370,18 @@ def main():
         dt_inst = time.perf_counter() - t1
         timing_on[0] = False
         module.model.engine.overlap_dw = overlap_was
-    if exchanging:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if exchanging:  # MAX over ranks, of the region and of every step
+        t = torch.tensor([dt] + step_ms, dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        dt, step_ms = float(t[0]), [float(x) for x in t[1:]]
     final_loss = float(loss.detach())
+    srt = sorted(step_ms)
+    median_ms = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    if rank == 0:
+        log("per-step ms (hipEvents on the launch stream): " + " ".join(f"{x:.2f}" for x in step_ms))
+        log("host issue ms per step: " + " ".join(f"{x:.2f}" for x in host_ms))
+        log(f"garbage collections inside the region: {gc_events}")
+        log(f"median {median_ms:.3f} ms, min {srt[0]:.3f}, max {srt[-1]:.3f}, region mean {dt / args.steps * 1e3:.3f} ms")
 
     # ---- N > 1: what the gradient exchange costs.  (a) the same steps with the exchange switched off (replicas drift
     # apart, which no longer matters: `value` is already taken), (b) the bare all-reduce of the flat gradient buffer in
@@ -291,12 +395,13 @@ def main():
                 "collectives_per_step": red.calls_per_step, "bytes_per_step": red.bytes_per_step}
         if not args.no_comm_probe:
             try:
-                comm.update(comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, dt))
+                comm.update(comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, median_ms))
             except Exception as e:  # noqa: BLE001 - the probe is extra evidence; `value` above is already measured
                 comm["probe_error"] = f"{type(e).__name__}: {e}"
 
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
+    mean_ms_per_step = dt / args.steps * 1e3
+    ms_per_step = median_ms
+    value = world * B / (median_ms * 1e-3)
     F = 4 * D
     flop_img = train_flop_per_image(L, P, D, layers, F)
 
@@ -360,7 +465,13 @@ def main():
         out = {
             "metric": "images/sec ViT-B/16 224^2 bf16 train step" if args.workload == "vit_b16_224" else f"images/sec {args.workload} bf16 train step",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+            "ms_per_step": round(ms_per_step, 3), "mean_ms_per_step": round(mean_ms_per_step, 3),
+            "timing": {"value_from": "median of per-step hipEvent times over the K timed steps (BASELINE.md section 2)",
+                       "min_ms": round(srt[0], 3), "max_ms": round(srt[-1], 3),
+                       "region_wall_ms": round(dt * 1e3, 3), "step_ms": [round(x, 3) for x in step_ms],
+                       "host_issue_ms": [round(x, 2) for x in host_ms], "gc_in_region": gc_events,
+                       "heap_frozen": not args.no_gc_freeze},
+            "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16-mixed" else "f32 (split-bf16 x3 MFMA)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "

@@ -149,3 +149,35 @@ def test_two_ranks_at_vit_b_geometry(tmp_path):
     eb = float((b[0]["grads"][:n].double() - g2).norm() / g2.norm())
     print(f"[ddp C3] 2-rank vs single grad rel err {e:.2e}; bf16 exchange vs fp32 exchange {eb:.2e}")
     assert 1e-4 < eb < 6e-3, eb
+
+
+def test_bench_two_ranks_reports_the_multi_gpu_probe():
+    """one `bench.py --gpus N` invocation must answer the open N > 1 questions by itself.  Two fresh ranks share
+    the GPU over gloo (same code path as under RCCL above the collective library) on the ViT-Tiny workload: the JSON line carries
+    the per-step event times, the median-based value, and inside `comm` the exchange-off step, the bare all-reduce, the
+    reserve_cus sweep, the zero1 schedule and the fixed-global-batch (strong scaling) step."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, VIT_DIST_BACKEND="gloo", VIT_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--workload", "vit_tiny16_32", "--batch", "512", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "weak" and doc["config"]["global_batch"] == 1024
+    tm = doc["timing"]
+    assert len(tm["step_ms"]) == 4 and tm["min_ms"] <= doc["ms_per_step"] <= tm["max_ms"]
+    assert abs(doc["value"] - 1024 / (doc["ms_per_step"] * 1e-3)) < 1e-2 * doc["value"]
+    comm = doc["comm"]
+    assert comm["backend"] == "gloo" and comm["world_size"] == 2 and "probe_error" not in comm, comm
+    assert [x["reserve_cus"] for x in comm["reserve_cus_sweep"]] == [0, 8, 16, 32]
+    for x in comm["reserve_cus_sweep"]:
+        assert x["ms_per_step"] > 0 and x["ms_per_step_exchange_off"] > 0
+    assert comm["zero1"][0]["reserve_cus"] == 0 and comm["zero1"][0]["ms_per_step"] > 0, comm
+    assert comm["strong_scaling"]["global_batch"] == 256 and comm["strong_scaling"]["per_gpu_batch"] == 128
+    assert comm["bare_allreduce_ms"] > 0 and comm["ms_per_step_exchange_off"] > 0

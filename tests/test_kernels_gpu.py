@@ -762,7 +762,12 @@ def test_attention_delta_residual(dev, B, H, T, dh):
 
 @pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 197, 64), (1, 2, 224, 64), (1, 2, 240, 32), (3, 1, 17, 64), (1, 2, 64, 64),
                                       (40, 12, 197, 64), (300, 1, 130, 64), (2, 3, 208, 64), (3, 2, 65, 64), (2, 2, 96, 64),
-                                      (64, 5, 177, 64)])  # (40, 12, ..), (300, 1, ..), (64, 5, ..): several heads per persistent workgroup
+                                      (64, 5, 177, 64),  # (40, 12, ..), (300, 1, ..), (64, 5, ..): several heads per persistent workgroup
+                                      # more heads than CUs at padded lengths R = 64, 96, 128, 160, 80, 112: the pair-pipelined kernel issues
+                                      # K / V pieces of the NEXT head in a head's LAST iteration there (none at R = 144, 176, 192, 208)
+                                      # and must wait for them before its closing barrier (r03 advisor finding: read-before-wait)
+                                      (300, 1, 64, 64), (300, 1, 96, 64), (300, 1, 128, 64), (300, 1, 160, 64), (150, 2, 75, 64),
+                                      (300, 1, 100, 64)])
 @pytest.mark.parametrize("drop", [(0.0, 0, 0), (0.1, 7, 5)])
 def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     """The single-kernel backward (one workgroup per head; dS through the LDS) against the dQ + dK/dV pair: same dropout

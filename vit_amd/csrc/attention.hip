@@ -1886,23 +1886,26 @@ __global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
 // every phase boundary from the critical path: the unit of work is a PAIR of query tiles (32 rows), one barrier per pair,
 // and in each barrier interval every stage of the backward runs for a DIFFERENT pair, on different waves:
 //
-//   iteration g:  top      B(g-1)   waves 6, 7: dQ of the two query tiles of pair g-1 = dS(g-1) K over all keys (dS image
+//   iteration g:  top      B(g-1)   waves 4-7: dQ of pair g-1 (wave 4 + j: query tile j >> 1, 16-column tiles 2 (j & 1), + 1)
+//                                   = dS(g-1) K over all keys (dS image
 //                                   [key][32 q] written by A(g-1), K^T by transposing reads of the head's K image); stores
 //                          E        every wave, when pair g-1 ended its head: dK / dV of its key tiles + bias-gradient sums
-//                 issue    L(g+2)   LDS-DMA of pair g+2's rows into ring slot (g+2) % 3: Q (waves 0-3, 8 rows each) and
-//                                   dO, O, O_lo, lse (waves 4-7, 8 rows each); KV(h+1): the next head's K and V images,
-//                                   a few pieces per wave per iteration
+//                 issue    L(g+2)   LDS-DMA of pair g+2's rows into ring slot (g+2) % 3: Q, dO, O, O_lo, lse of 8 rows per wave,
+//                                   ALL issued by waves 0-3 (waves 4-7 issue nothing: they carry B); KV(h+1): the next head's
+//                                   K and V images, a few pieces per issuing wave per iteration (pairs 1 .. np-1 of head h)
 //                 A(g)              every wave, owner = key (tiles w and w + 8): S = Q K^T, dP = dO V^T, P, dS; dV += P^T dO,
 //                                   dK += dS^T Q in registers; dS (bf16) -> dS image g % 2.  K / V fragments are read from the
 //                                   LDS images when a head starts.  This is the VALU-bound stage; all else hides under it.
-//                 wait              s_waitcnt vmcnt(n): n = what THIS iteration issued, so L(g+1) (one iteration old) is in
-//                 D(g+1)   waves 4-7: delta = rowsum(dO (O + O_lo)), lse * log2 e, dropout row keys of the 8 rows whose
+//                 wait              s_waitcnt vmcnt(n): n = what THIS iteration issued, so L(g+1) (one iteration old) is in; in a
+//                                   head's last iteration n excludes the K / V pieces issued in it (issued first: they are
+//                                   read at the top of the next iteration's A stage, before that iteration's wait)
+//                 D(g+1)   waves 0-3: delta = rowsum(dO (O + O_lo)), lse * log2 e, dropout row keys of the 8 rows whose
 //                                   data the wave loaded ITSELF (its own vmcnt wait orders them: no barrier needed)
 //                 barrier           publishes dS(g), statistics(g+1), the landed rows of pair g+1
 //
 // Nothing younger than an iteration's DMA is a store (stores sit at the top of the next iteration), so the counted wait
-// never drains a store or a prefetch.  13 key tiles at T = 197: waves 0-4 own two, waves 5-7 one -- and waves 4-7 carry the
-// D / B stages, so the four SIMDs (waves w and w + 4) are loaded about evenly.  Rows past T: DMA sources are clamped to row
+// never drains a store or a prefetch.  13 key tiles at T = 197: waves 0-3 and wave 7 own two, waves 4-6 one -- waves 0-3 carry
+// the DMA issue and D, waves 4-7 the B stage, so the four SIMDs (waves w and w + 4) are loaded about evenly.  Rows past T: DMA sources are clamped to row
 // T - 1, their probabilities are zero through lse = +inf (queries) / +inf added on the key side.
 // LDS: ring 3 x 16 KiB + lse staging 3 KiB + 2 K images + V image + 2 dS images [R][32] + statistics = 156 KiB at R = 208.
 // dh = 64, 64 <= T <= 208.  Deterministic, no atomics (basemodule.py:250).
@@ -1976,8 +1979,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
   const float c = p.scale * LOG2E;
   const bool has_lo = LOC || p.ctx_lo != nullptr;
   const float dscale = p.drop.thr ? p.drop.scale : 1.0f;  // 1 / (1 - p) of the kept probabilities
-  // roles: waves 0-3 load dO / O / O_lo / lse of 8 rows each and derive their statistics (D); waves 4-7 load Q and run the
-  // dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
+  // roles: waves 0-3 issue EVERY DMA piece (Q / dO / O / O_lo / lse of 8 rows each, and the next head's K / V) and derive the
+  // statistics of the rows they loaded (D); waves 4-7 issue nothing and run the dQ stage (B): wave 4 + j takes query tile j >> 1 of the pair and the two 16-column tiles 2 (j & 1), 2 (j & 1) + 1 of dQ
   const bool is_d = wave < 4, is_b = wave >= 4;
   const int grp = wave & 3;
   // this wave's key tiles: tile w, and of the tiles past 8 first the four for waves 0-3, then wave 7, 6, 5, 4 -- waves 4-7 carry
@@ -2192,7 +2195,13 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     }
     PIPE_ST(0)  // top: B(g-1) + head-end epilogue
     // ------------------------------------------------------------------ issue: next head's K / V images, pair g + 2
-    int nissued = 0;
+    // INVARIANT of every hand-counted wait below: a DMA piece may be read only after a wait of the wave that issued it AND a
+    // barrier, both at least one iteration newer than its issue.  L pieces: issued in iteration g for pair g + 2, covered by
+    // the wait of iteration g + 1 (which leaves only ITS OWN issues in flight), read from iteration g + 2 on.  K / V pieces of
+    // the next head are read at the TOP of that head's first A stage, i.e. before that iteration's wait: the ones issued in a
+    // head's LAST iteration are therefore waited for in that same iteration (they are issued before the L pieces and vmcnt
+    // retires in order, so the wait leaves only the L pieces in flight; the whole A stage lies between issue and wait).
+    int nissued = 0, nkv_now = 0;
     if (g == -2) {  // prologue: the first head's images, spread over the waves
       const int per = (kv_total + 7) >> 3;
       nissued += issue_KV(q2, 0, wave * per, per);
@@ -2201,7 +2210,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
         Hn = head_of(h0 + 1);
         qn = qoff_of(Hn);
       }
-      nissued += issue_KV(qn, (h0 + 1) & 1, ((p0 - 1) * 4 + wave) * kvp, kvp);
+      const int n_ = issue_KV(qn, (h0 + 1) & 1, ((p0 - 1) * 4 + wave) * kvp, kvp);
+      nissued += n_;
+      if (p0 == np - 1) nkv_now = n_;  // the head's last iteration: these must have landed before its closing barrier
     }
     if (v2 && !(VIT_PIPE_SKIP & 4)) nissued += issue_L(H2.bh, q2, c2, p2, (g + 2) % PIPE_NS);
     PIPE_ST(1)  // DMA issue
@@ -2291,7 +2302,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pipe_kernel(AttnArgs p) {
     }
     PIPE_ST(2)  // A(g)
     // ------------------------------------------------------------------ my pieces of pair g + 1 (one iteration old) are in
-    wait_vmcnt_dyn(nissued);
+    wait_vmcnt_dyn(nissued - nkv_now);
     PIPE_ST(3)  // counted wait
     // ------------------------------------------------------------------ D(g+1): statistics of the 8 rows this wave loaded
     if (v1 && is_d && !(VIT_PIPE_SKIP & 8)) {

@@ -219,11 +219,11 @@ __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst) {
 #else
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst /* wave-uniform */) {
   const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst /* wave-uniform */) {
   const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(a) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(a) : "memory", "m0");
 }
 #endif
 // The same two with a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: the lane address is one
@@ -234,11 +234,11 @@ __device__ __forceinline__ void lds_dma4(const void* gsrc, void* lds_dst /* wave
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ __forceinline__ void lds_dma16_s(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_addr /* wave-uniform */) {
   const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
 }
 __device__ __forceinline__ void lds_dma4_s(const void* sbase /* wave-uniform */, unsigned voff, unsigned lds_addr /* wave-uniform */) {
   const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
 }
 
 // the handle's bound per-step state (api.hip): [key0, key1, lr, bc1, rsqrt_bc2, step] in device memory, or NULL

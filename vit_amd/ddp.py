@@ -151,7 +151,9 @@ class GradAllReducer:
                 if t.is_cuda:  # gloo reads the tensor on the host side: the producing kernels must have finished
                     torch.cuda.current_stream(t.device).synchronize()
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._pending.append((w, t, back, 1.0 / self.world))
+                # fp32 path: scale None = DIVIDE by the world size at the join, as torch-DDP does (x / 3 and x * (1/3) differ
+                # in the last bit); the multiplicative scale exists only for the bf16 cast-back kernel
+                self._pending.append((w, t, back, (1.0 / self.world) if back is not None else None))
             self.bytes_reduced += t.numel() * t.element_size()
         self._seen += 1
 
@@ -161,8 +163,8 @@ class GradAllReducer:
             w.wait()
             if back is not None:  # bf16 exchange: back into the fp32 gradient buffer (and the mean, where the library summed)
                 self._from_bf16(t, back, scale)
-            elif scale != 1.0:
-                t.mul_(scale)
+            elif scale is None:
+                t.div_(self.world)
         self._pending = []
         self._seen = 0
 
@@ -187,6 +189,7 @@ class ShardedGradReducer(GradAllReducer):
         self.mode = "zero1"
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.sharded = [(hi - lo) > 0 and (hi - lo) % (8 * self.world) == 0 for lo, hi in buckets]
+        self._sharded_of = {(lo, hi): sh for (lo, hi), sh in zip(buckets, self.sharded)}
         self.calls_per_step = sum(1 for lo, hi in buckets if hi > lo)
         self.gather_calls_per_step = sum(self.sharded)
 
@@ -195,7 +198,7 @@ class ShardedGradReducer(GradAllReducer):
         return lo + self.rank * c, lo + (self.rank + 1) * c
 
     def is_sharded(self, lo: int, hi: int) -> bool:
-        return self.active and self.sharded[self.buckets.index((lo, hi))]
+        return self.active and self._sharded_of[(lo, hi)]
 
     def bucket_ready(self, lo: int, hi: int):
         if not self.active or hi <= lo:
