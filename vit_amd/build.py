@@ -68,7 +68,7 @@ def build(force: bool = False, verbose: bool = True, diag: bool = False, stamps:
     if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
         return LIB
     hipcc = _hipcc()
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-comment", "-DNDEBUG"]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wno-comment", "-Wno-inline-asm", "-DNDEBUG"]
     if stamps:  # in-kernel s_memtime stamps in the ping-pong GEMM (1 = per segment, 2 = also inside the LOAD segment)
         flags.append(f"-DVIT_PP_STAMP={int(stamps)}")
     elif diag:

@@ -486,46 +486,6 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict
 // LDS-read and barrier bound at ~135 TFLOP/s).
 // Stage two [T, dh] matrices (all their 64-row tiles) at once: every global load of a thread is issued before its first
 // LDS store, so a workgroup pays ONE memory latency for its whole working set (a load->store loop paid ten).
-// column sums of a wave's 16-row x 4-column register tile over its rows (lanes that share lane >> 4), bf16-rounded like
-// the stored values; the four lanes with l15 == 0 hold the result
-__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
-  // v + (v moved within its 16-lane row): DPP moves are plain VALU ops; __shfl_xor goes through ds_bpermute (LDS crossbar)
-  int m;
-  const int iv = __builtin_bit_cast(int, v);
-  switch (ctrl_sel) {
-    case 0: m = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, false); break;   // row_ror:8
-    case 1: m = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xF, 0xF, false); break;   // row_ror:4
-    case 2: m = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
-    default: m = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
-  }
-  return v + __builtin_bit_cast(float, m);
-}
-// sum over groups of CPR (4 or 8) consecutive lanes, result in every lane of the group: quad swaps, then (8) the mirror of the
-// 8-lane half row brings the other quad's sum
-template <int CPR>
-__device__ __forceinline__ float sum_lanes_cpr(float x) {
-  x = dpp_add(x, 3);
-  x = dpp_add(x, 2);
-  if (CPR == 8) {
-    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false);  // row_half_mirror
-    x += __builtin_bit_cast(float, m);
-  }
-  return x;
-}
-__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {  // every lane ends with the sum over its 16-lane row
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    float x = v[c];
-    x = dpp_add(x, 0); x = dpp_add(x, 1); x = dpp_add(x, 2); x = dpp_add(x, 3);
-    v[c] = x;
-  }
-  return v;
-}
-__device__ __forceinline__ f32x4 bf_round4(u32x2 pk) {
-  return (f32x4){__builtin_bit_cast(float, pk[0] << 16), __builtin_bit_cast(float, pk[0] & 0xFFFF0000u),
-                 __builtin_bit_cast(float, pk[1] << 16), __builtin_bit_cast(float, pk[1] & 0xFFFF0000u)};
-}
-
 template <int DH>
 __device__ __forceinline__ void load_all_tiles2(char* imgA, const short* ga, long lda, char* imgB, const short* gb,
                                                 long ldb, int T, int dh, int rows_alloc, int tid, int nthr) {
@@ -589,19 +549,6 @@ __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, i
     // uniform base + 32-bit lane offset (rows x row stride x 2 B stays far below 2^32 inside one head's rows), raw LDS address
     lds_dma16_s(g, __umul24((unsigned)grow, (unsigned)(ld * 2)) + (unsigned)(c * 16), img_a + j * 1024);
   }
-}
-
-// Two adjacent 16-column tiles of one 16-row block, packed to bf16 (a lane holds 4 consecutive columns of each: 8 bytes + 8
-// bytes), into ONE 16-byte store per lane: v_permlane16_swap trades the odd lane groups' first-tile data for the even
-// groups' second-tile data, so an even group ends with 8 consecutive columns of the first tile, an odd group with 8 of the
-// second.  Row-per-lane stores are issue-bound (each instruction touches 16 rows): half the instructions, half the time.
-// Returns this lane's first column within the 32-column pair.
-__device__ __forceinline__ int widen_pair(u32x2& a, u32x2& b, int lg) {
-  auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-  auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-  a[0] = r0[0]; b[0] = r0[1];
-  a[1] = r1[0]; b[1] = r1[1];
-  return (lg & 1) ? 16 + 4 * (lg - 1) : 4 * lg;
 }
 
 // lo = bf16(v - bf16(v)) for 4 values already packed as pk (the context residual), returned packed

@@ -183,6 +183,61 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- lane movement inside 16-lane rows (DPP) and between them (v_permlane16_swap); shared by the attention kernels and the
+// GEMM epilogues
+// column sums of a wave's 16-row x 4-column register tile over its rows (lanes that share lane >> 4), bf16-rounded like
+// the stored values; the four lanes with l15 == 0 hold the result
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+  // v + (v moved within its 16-lane row): DPP moves are plain VALU ops; __shfl_xor goes through ds_bpermute (LDS crossbar)
+  int m;
+  const int iv = __builtin_bit_cast(int, v);
+  switch (ctrl_sel) {
+    case 0: m = __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, false); break;   // row_ror:8
+    case 1: m = __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xF, 0xF, false); break;   // row_ror:4
+    case 2: m = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    default: m = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, false); break;   // quad_perm [1,0,3,2]
+  }
+  return v + __builtin_bit_cast(float, m);
+}
+// sum over groups of CPR (4 or 8) consecutive lanes, result in every lane of the group: quad swaps, then (8) the mirror of the
+// 8-lane half row brings the other quad's sum
+template <int CPR>
+__device__ __forceinline__ float sum_lanes_cpr(float x) {
+  x = dpp_add(x, 3);
+  x = dpp_add(x, 2);
+  if (CPR == 8) {
+    const int m = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false);  // row_half_mirror
+    x += __builtin_bit_cast(float, m);
+  }
+  return x;
+}
+__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {  // every lane ends with the sum over its 16-lane row
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = v[c];
+    x = dpp_add(x, 0); x = dpp_add(x, 1); x = dpp_add(x, 2); x = dpp_add(x, 3);
+    v[c] = x;
+  }
+  return v;
+}
+__device__ __forceinline__ f32x4 bf_round4(u32x2 pk) {
+  return (f32x4){__builtin_bit_cast(float, pk[0] << 16), __builtin_bit_cast(float, pk[0] & 0xFFFF0000u),
+                 __builtin_bit_cast(float, pk[1] << 16), __builtin_bit_cast(float, pk[1] & 0xFFFF0000u)};
+}
+
+// Two adjacent 16-column tiles of one 16-row block, packed to bf16 (a lane holds 4 consecutive columns of each: 8 bytes + 8
+// bytes), into ONE 16-byte store per lane: v_permlane16_swap trades the odd lane groups' first-tile data for the even
+// groups' second-tile data, so an even group ends with 8 consecutive columns of the first tile, an odd group with 8 of the
+// second.  Row-per-lane stores are issue-bound (each instruction touches 16 rows): half the instructions, half the time.
+// Returns this lane's first column within the 32-column pair.
+__device__ __forceinline__ int widen_pair(u32x2& a, u32x2& b, int lg) {
+  auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  a[0] = r0[0]; b[0] = r0[1];
+  a[1] = r1[0]; b[1] = r1[1];
+  return (lg & 1) ? 16 + 4 * (lg - 1) : 4 * lg;
+}
+
 // ---- reductions across the 4 lane groups lane>>4 (all 64 lanes end with the result)
 __device__ __forceinline__ float grp4_max(float x) {
   x = fmaxf(x, __shfl_xor(x, 16, 64));
@@ -207,8 +262,11 @@ constexpr unsigned OOB = 0x80000000u;  // any voffset >= num_records reads as ze
 // of the first ds_read_b64_tr_b16 that follows -- once per K-tile phase in every GEMM with a transposed operand (dX, dW), and
 // in the attention kernels: the whole ring was drained although the hand-counted waits left 64 KiB in flight (r03 finding:
 // ISA of gemm3_kernel<*,1,*,*>; the plain ds_read_b128 forms were never affected).  The asm form is invisible to that pass;
-// these loads still count in vmcnt, in order, and every wait for them is a hand-counted s_waitcnt.  M0 is reserved by the
-// compiler and not otherwise used by these kernels; it is written in the statement that reads it (s_nop: M0 write -> use).
+// these loads still count in vmcnt, in order, and every wait for them is a hand-counted s_waitcnt.  M0 is written in the
+// statement that reads it (s_nop: M0 write -> use) and named in the clobber list (r04, advisor finding): the compiler's own
+// users of M0 (its LDS-DMA builtin in the VIT_DMA_BUILTIN variant, v_readlane / v_movrel indexing, s_sendmsg) then see a
+// definition here and neither keep a value live across the statement nor drop their own M0 write as redundant.  clang notes
+// that M0 is a reserved register (-Winline-asm, silenced in build.py): it is not allocatable, the clobber is still recorded.
 #ifdef VIT_DMA_BUILTIN  // A/B variant build only (python -m vit_amd.build --defs -DVIT_DMA_BUILTIN --tag dmab): the builtin form
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);

@@ -195,6 +195,20 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
   // wave-instruction covers 8 whole 128-byte row segments (the epilogue is store-ISSUE bound: half as many, twice as wide)
   const int cg = lane & 7, rsub = lane >> 3;
   const int n = n0 + cg * 8;
+  // The outputs leave through raw buffer stores with the sc1 bit: write-through, and the line is NOT kept in the XCD's L2
+  // (MI355X_MICROARCH.md, "stores of each flavour").  An epilogue's output is a write-once stream of 77-620 MB per launch that
+  // nobody in this launch reads again; kept in the 4 MiB L2 it evicts the operand panels the XCD's other workgroups are about
+  // to re-read.  r04, same-box A/B against plain stores (tools/gemm_bench.py, two interleaved repetitions): FC1 + GELU (two
+  // outputs, 620 MB) 284-286 -> 271-275 us, the K = 768 / N = 768 products 70 -> 66 and 62 -> 60.7 us, QKV 160.6 -> 159.
+#ifndef VIT_EPI_PLAIN_STORES
+  const __amdgpu_buffer_rsrc_t rc_ = make_rsrc(p.C, (unsigned long long)p.M * p.ldc * 2);
+  const __amdgpu_buffer_rsrc_t ra_ = make_rsrc(p.aux_out ? (const void*)p.aux_out : (const void*)p.C, (unsigned long long)p.M * p.ldaux * 2);
+#define EPI_STORE_C(M_, PK) __builtin_amdgcn_raw_buffer_store_b128(PK, rc_, (unsigned)(((M_) * p.ldc + n) * 2), 0, 16)
+#define EPI_STORE_AUX(M_, PK) __builtin_amdgcn_raw_buffer_store_b128(PK, ra_, (unsigned)(((M_) * p.ldaux + n) * 2), 0, 16)
+#else  // A/B variant build only
+#define EPI_STORE_C(M_, PK) *(u32x4*)(p.C + ((M_) * p.ldc + n) * 2) = PK
+#define EPI_STORE_AUX(M_, PK) *(u32x4*)(p.aux_out + (M_) * p.ldaux + n) = PK
+#endif
   const unsigned half_cols = (unsigned)(p.N >> 1);
   f32x4 bv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
   if ((FAST == 3 || FAST == 4) && p.bias) {
@@ -204,6 +218,14 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // column sums of the stored (bf16-rounded) values
   const bool want_cs = p.colsum_part != nullptr;
   u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
+  // the aux operand (gelu' of FC1's pre-activation, 310 MB) is read exactly once: nt + sc1 keeps it out of L1 / low priority in
+  // L2 (r04 A/B on dX * gelu', same box: plain 338 us, nt 333, nt + sc1 327-330).  0 = plain loads (A/B variant)
+#ifndef VIT_EPI_AUX_POLICY
+#define VIT_EPI_AUX_POLICY 18
+#endif
+#if VIT_EPI_AUX_POLICY
+  const __amdgpu_buffer_rsrc_t rx_ = make_rsrc(p.aux_in ? (const void*)p.aux_in : (const void*)p.C, (unsigned long long)p.M * p.ldaux * 2);
+#endif
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     if (FAST == 5 && (i & 3) == 0) {
@@ -211,7 +233,11 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
+#if VIT_EPI_AUX_POLICY
+          au[ii][rr] = __builtin_amdgcn_raw_buffer_load_b128(rx_, (unsigned)(((long)(m0 + (i + ii) * 16 + rr * 8 + rsub) * p.ldaux + n) * 2), 0, VIT_EPI_AUX_POLICY);
+#else
           au[ii][rr] = *(const u32x4*)(p.aux_in + (long)(m0 + (i + ii) * 16 + rr * 8 + rsub) * p.ldaux + n);
+#endif
     }
     f32x4 v[2][2];
 #ifdef VIT_EPI_NOLDS  // timing experiment (compile-time variant): no LDS transpose, values land in the wrong places
@@ -274,7 +300,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
         if (p.aux_out) {
 #endif
           u32x4 pk = {pack2bf(sv[0], sv[1]), pack2bf(sv[2], sv[3]), pack2bf(sv[4], sv[5]), pack2bf(sv[6], sv[7])};
-          *(u32x4*)(p.aux_out + m * p.ldaux + n) = pk;
+          EPI_STORE_AUX(m, pk);
         }
       }
       if (FAST == 5) {
@@ -303,7 +329,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
         }
       }
       u32x4 pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
-      *(u32x4*)(p.C + (m * p.ldc + n) * 2) = pk;
+      EPI_STORE_C(m, pk);
       if (want_cs) {  // uniform: only the launches that fuse a bias gradient pay the unpack + add per stored vector
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -330,6 +356,8 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
       *(f32x4*)(dst + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
     }
   }
+#undef EPI_STORE_C
+#undef EPI_STORE_AUX
 }
 
 // ------------------------------------------------------------------------------------------------ ping-pong variant
@@ -1177,6 +1205,11 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_BF16 && !d->a_trans && d->b_trans &&
              splits == 1) epi5 = 6;
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_F32 && d->a_trans && d->b_trans) epi5 = 7;
+    // the bf16 fast epilogues store through 32-bit buffer offsets (raw buffer stores, sc1): outputs past 2 GiB keep the
+    // generic epilogue (a clamped descriptor would drop the stores beyond it silently)
+    if (epi5 >= 3 && epi5 <= 6 &&
+        ((unsigned long long)d->M * d->ldc * 2 >= 0x7FFFFFF0ull || (d->aux_out && (unsigned long long)d->M * d->ldaux * 2 >= 0x7FFFFFF0ull)))
+      epi5 = epi;
   }
   // the tiles of a partial last round go to the half-tile kernel (two workgroups per tile) when the epilogue is one of
   // the kinds instantiated for it and nothing else rides on the launch
