@@ -52,9 +52,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *                64) run the 256x256x64 ping-pong core (wave halves one barrier out of phase: LOAD segment beside MFMA
  *                segment, ring of 8 half-tiles, 4 in flight); 5 = the same choice named explicitly.
  *   "attn_split": workgroups per (batch, head) in the resident attention kernels (T <= 256), default 2.
- *   "attn_bwd_fused": attention backward form: 4 (default) = the pair-pipelined single kernel where it fits (head_dim 64,
- *                64 <= T <= 208), else as 3; 3 = the persistent single kernel (head_dim 64, T <= 224), else as 1; 1 / 2 = the
- *                fused single kernel with 8 / 16 waves (T <= 240); 0 = the dQ + dK/dV pair.
+ *   "attn_bwd_fused": attention backward form: non-zero (default 4) = the pair-pipelined single kernel where it fits (head_dim
+ *                64, 64 <= T <= 208), the dQ + dK/dV pair elsewhere; 0 = the dQ + dK/dV pair everywhere.  (The values 1 .. 3
+ *                named the single-kernel forms of round 2, removed in round 4; they are accepted and mean the default.)
  *   "attn32_mfma": 1 (default) = fp32 attention (precision '32') at head_dim 64 runs on the f32-input matrix instructions
  *                (v_mfma_f32_16x16x4_f32: exact f32 products and accumulation); 0 = the one-wave-per-row vector kernels.
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.

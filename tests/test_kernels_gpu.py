@@ -783,9 +783,8 @@ def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
     dctx = bf(randn((B * T, H * dh), dev, 71))
     out = {}
     try:
-        # two-kernel path, fused with 8 / 16 waves, persistent form (dh = 64, T <= 224), pair-pipelined form (dh 64, 64 <= T <= 208;
-        # elsewhere 4 falls through to 3 / 1)
-        for fused in (0, 1, 2, 3, 4):
+        # two-kernel path and the pair-pipelined single kernel (dh 64, 64 <= T <= 208; elsewhere 4 is the two-kernel path too)
+        for fused in (0, 4):
             _cabi.set_option("attn_bwd_fused", fused)
             cs = torch.zeros(3 * H * dh, device=dev)
             delta = torch.zeros((B * H, T), device=dev)
@@ -793,10 +792,7 @@ def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
             out[fused] = (d.clone(), cs.clone(), delta.clone())
     finally:
         _cabi.set_option("attn_bwd_fused", 4)
-    a, b_ = out[0], out[1]
-    for k in (2, 3, 4):
-        assert rel(out[k][0], a[0]) < 6e-3 and rel(out[k][2], a[2]) < 1e-5, k
-        assert rel(out[k][1], out[k][0].float().sum(0)) < 1e-5, k
+    a, b_ = out[0], out[4]
     assert rel(b_[0], a[0]) < 6e-3, rel(b_[0], a[0])
     assert rel(b_[2], a[2]) < 1e-5
     assert rel(b_[1], b_[0].float().sum(0)) < 1e-5  # column sums of what was stored

@@ -666,3 +666,73 @@ def test_full_size_vit_b_training_step(dev):
     moved = [k for k, v in module.model.state_dict().items() if not torch.equal(v, w0[k])]
     frozen = [k for k in w0 if k not in moved]
     assert all("pooler" in k for k in frozen), frozen  # the pooler is never used (SURVEY section 8 e): everything else moved
+
+
+def test_full_size_vit_l_training_step(dev):
+    """BASELINE config 5 at its own batch under -m gpu ('C5 at its BASELINE batch (B = 32) runs only in the
+    builder's bench.py'): ViT-L/16 384^2 restated (L = 147456, 576 + 1 tokens, 24 x 1024, 16 heads, MLP 4096), B = 32,
+    bf16-mixed, one rank -- the shape that takes the resident attention kernels at T = 577 (two-kernel backward), the 292-tile
+    products with a 36-tile split-K tail and the D = 1024 LayerNorm forms.  Size-independent properties at full size:
+    (1) dropout off: two runs from the same seed give the same losses and clipped gradient norms bit for bit;
+    (2) dropout off: the training-mode loss of step 0 is the evaluation-mode loss of the same weights and batch;
+    (3) the loss is a mean over samples: L(32) = mean of the two half-batch losses to bf16 rounding (other tile counts, hence
+        other summation orders in the tail tiles);
+    (4) dropout on: three steps stay finite, the clipped norm is reported, every trainable tensor moves.  (The loss itself
+        jumps after the first AdamW step -- 303 M weights each move by lr along the gradient's sign with no warm-up, in the
+        reference as here -- so it is not asserted to fall.)"""
+    import vit_amd.functional  # noqa: F401
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    L = 147456
+
+    def cfg(B):
+        return {
+            "model": dict(name="vit", task_type="reg", image_size=L, patch_size=256, hidden_size=1024, num_hidden_layers=24,
+                          num_attention_heads=16, stride_size=256, proj_fn="SW"),
+            "train": dict(batch_size=B, ep=1, precision="bf16-mixed"),
+            "loss": {"name": "mae"}, "opt": {"type": "AdamW", "lr": 1e-4}, "data": {"param": "log_g"},
+            "noise": {"noise_level": 0},
+        }
+
+    g = torch.Generator().manual_seed(4321)
+    flux, err, lab = torch.randn(32, L, generator=g).cuda(), (0.1 * torch.rand(32, L, generator=g)).cuda(), \
+        torch.rand(32, generator=g).cuda()
+
+    def run(B, dropout, steps, sl=slice(None)):
+        seed_everything(42)
+        module = ViTLModule(config=cfg(B))
+        assert sum(p.numel() for p in module.parameters()) > 300e6  # SURVEY 8: 303.6 M parameters
+        if not dropout:
+            module.model.config.hidden_dropout_prob = 0.0
+            module.model.config.attention_probs_dropout_prob = 0.0
+        trainer = Trainer(cfg(B)["train"], device=torch.device("cuda", 0), verbose=False)
+        trainer._setup(module)
+        module.eval()
+        with torch.no_grad():
+            ev = float(module(flux[sl], labels=lab[sl]))
+        module.train()
+        w0 = {k: v.detach().clone() for k, v in module.model.state_dict().items()} if dropout else None
+        out = []
+        for i in range(steps):
+            out.append((float(trainer.training_step(module, (flux[sl], err[sl], lab[sl]), i)),
+                        float(trainer.optimizer.last_grad_norm)))
+        return ev, out, w0, module
+
+    ev_a, a, _, m = run(32, False, 2)
+    del m
+    ev_b, b, _, m = run(32, False, 2)
+    del m
+    assert a == b and ev_a == ev_b, (a, b)                                    # (1)
+    assert abs(a[0][0] - ev_a) <= 1e-6 * max(1.0, abs(ev_a)), (a[0][0], ev_a)   # (2)
+    ev_lo, _, _, m = run(16, False, 0, slice(0, 16))
+    del m
+    ev_hi, _, _, m = run(16, False, 0, slice(16, 32))
+    del m
+    assert abs(0.5 * (ev_lo + ev_hi) - ev_a) <= 5e-3 * abs(ev_a), (ev_lo, ev_hi, ev_a)  # (3)
+    torch.cuda.empty_cache()
+    _, d, w0, module = run(32, True, 3)
+    assert all(np.isfinite(l) and np.isfinite(n) and n > 0 for l, n in d), d   # (4)
+    moved = [k for k, v in module.model.state_dict().items() if not torch.equal(v, w0[k])]
+    frozen = [k for k in w0 if k not in moved]
+    assert all("pooler" in k for k in frozen), frozen

@@ -25,12 +25,6 @@ namespace vit {
 
 void* ctx_workspace(vit_handle h, size_t* bytes);
 
-// Timing variants of the fused / persistent backward kernels are COMPILE-TIME builds (python -m vit_amd.build --defs
-// -DVIT_ATTN_SKIP=n --tag name; bits: 1 no phase B, 2 no phase A, 4 no operand staging, 8 no dK/dV stores, 16 / 32 (persistent
-// form) no K/V-row and delta-chunk loads / no lse loads and delta stores); the product library has no such switch.
-#ifndef VIT_ATTN_SKIP
-#define VIT_ATTN_SKIP 0
-#endif
 constexpr int AW = 4;    // waves per workgroup
 constexpr int RT = 64;   // rows per LDS tile
 constexpr float LOG2E = 1.4426950408889634f;
@@ -1238,599 +1232,14 @@ __device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, const u32x
   }
 }
 
-// dS image of the fused backward kernels: [key][128 queries] bf16, 256 bytes per key row, the 8-byte slot (4 consecutive
-// queries of one key: what a phase-A lane stores and a phase-B lane's transposing read fetches) XOR-swizzled by the key:
-//  * phase-A store (ds_write_b64, banks mod 32, 16-lane groups = 16 consecutive keys at ONE slot): slot ^ x must differ
-//    mod 16 between the 16 keys -> x mod 16 = a bijection of key & 15;
-//  * phase-B read (ds_read_b64_tr_b16, banks mod 64, a 32-lane half = 8 consecutive keys x 4 adjacent slots): the
-//    32-byte group index (slot >> 2) ^ (x >> 2) must differ between the 8 keys -> x >> 2 = key & 7.
-// x = ((key & 7) << 2) | ((key >> 2) & 3) does both (r03; the padded 288-byte rows before it stored 4-way conflicted).
-constexpr int DSP = 256;
-__device__ __forceinline__ int ds_swz(int key) { return ((key & 7) << 2) | ((key >> 2) & 3); }
-__device__ __forceinline__ int ds_off(int key, int slot) { return key * DSP + ((slot ^ ds_swz(key)) << 3); }
-
-template <int DH>
-__device__ __forceinline__ void load_all_tiles3(char* imgA, const short* ga, long lda, char* imgB, const short* gb, long ldb,
-                                                char* imgC, const short* gc, long ldc_, int T, int dh, int rows_alloc, int tid,
-                                                int nthr) {
-  constexpr int CPR = DH / 8, MAXI = 4;
-  const int total = rows_alloc * CPR;
-  for (int base = 0; base < total; base += MAXI * nthr) {
-    i32x4 va[MAXI], vb[MAXI], vc[MAXI];
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      const int q = base + tid + i * nthr;
-      const int r = q / CPR, c = q % CPR;
-      va[i] = vb[i] = vc[i] = (i32x4){0, 0, 0, 0};
-      if (q < total && r < T && c * 8 < dh) {
-        va[i] = *(const i32x4*)(ga + (long)r * lda + c * 8);
-        vb[i] = *(const i32x4*)(gb + (long)r * ldb + c * 8);
-        vc[i] = *(const i32x4*)(gc + (long)r * ldc_ + c * 8);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-      const int q = base + tid + i * nthr;
-      if (q < total) {
-        const int r = q / CPR, c = q % CPR;
-        const int off = (r >> 6) * (RT * DH * 2) + tile_off<DH>(r & 63, c);
-        *(i32x4*)(imgA + off) = va[i];
-        *(i32x4*)(imgB + off) = vb[i];
-        *(i32x4*)(imgC + off) = vc[i];
-      }
-    }
-  }
-}
-
-// NW waves per workgroup: 8 (each wave owns 32 keys, two 16-key tiles) or 16 (16 keys each: half the registers per wave,
-// so 4 waves per SIMD instead of 2 hide the LDS / MFMA / exp latencies the 2-wave form showed as 42 % parked wave-cycles)
-template <int DH, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs p) {
-  resolve_drop(p.drop);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TILE = RT * DH * 2, RQ = 16 / NW, CPR = DH / 8, RPI = NW * 64 / CPR /* rows per delta iteration */;
-  constexpr int DIT = (240 + RPI - 1) / RPI, ND = DH / 16, WPQ = NW / 8 /* waves per query tile in phase B */, DPW = ND / WPQ;
-  static_assert(DPW >= 1, "phase B: at least one d-tile per wave");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  // workgroups of one XCD (blockIdx % 8) take consecutive heads: neighbours in time share that XCD's L2 for the weights of
-  // nothing -- but the (batch, head) order keeps a sample's rows of qkv / dctx together in one L2
-  const int nwg = gridDim.x;
-  const int bh = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int T = p.T, dh = p.dh;
-  const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
-  const short* qb = p.qkv + (long)b * T * ld + h * dh;
-  const short* kb_ = qb + p.H * dh;
-  const short* vb = kb_ + p.H * dh;
-  const short* dob = p.dctx + (long)b * T * ldc + h * dh;
-  const short* ob = p.ctx + (long)b * T * ldc + h * dh;
-  const int R = (T + 15) & ~15;
-  char* Qimg = smem;
-  char* Oimg = smem + R * (DH * 2);
-  char* Kimg = smem + 2 * R * (DH * 2);
-  char* dSimg = smem + 3 * R * (DH * 2);
-  float* lse_s = (float*)(dSimg + R * DSP);
-  float* del_s = lse_s + R;
-  unsigned* rk_s = (unsigned*)(del_s + R);  // dropout row keys of the head's query rows
-
-  // ---- loads in flight before the first barrier: this wave's K / V rows, the O (+ residual) chunks of the delta pre-pass
-  const int k00 = wave * RQ * 16;
-  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
-#pragma unroll
-  for (int rq = 0; rq < RQ; ++rq) {
-    load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, dh, l15, lg);
-    load_own<DH>(vf[rq], vb, ld, k00 + rq * 16, T, dh, l15, lg);
-  }
-  i32x4 og[DIT], ol[DIT];
-  const int drow0 = wave * (64 / CPR) + lane / CPR, dch = lane % CPR;
-#pragma unroll
-  for (int it = 0; it < DIT; ++it) {
-    const int row = drow0 + it * RPI;
-    og[it] = ol[it] = (i32x4){0, 0, 0, 0};
-    if (row < T && dch * 8 < dh) {
-      og[it] = *(const i32x4*)(ob + (long)row * ldc + dch * 8);
-      if (p.ctx_lo) ol[it] = *(const i32x4*)(p.ctx_lo + (ob - p.ctx) + (long)row * ldc + dch * 8);
-    }
-  }
-  if (!(VIT_ATTN_SKIP & 4)) load_all_tiles3<DH>(Qimg, qb, ld, Oimg, dob, ldc, Kimg, kb_, ld, T, dh, R, tid, NW * 64);
-  __syncthreads();
-  // ---- delta[q] = sum_d dO[q,d] (O[q,d] + O_lo[q,d]), lse in the exp2 domain
-#pragma unroll
-  for (int it = 0; it < DIT; ++it) {
-    const int row = drow0 + it * RPI;
-    if (row < R) {  // whole CPR-lane groups share `row`: the shuffles below stay inside the group
-      const bf16x8 dv = *(const bf16x8*)(Oimg + (row >> 6) * TILE + tile_off<DH>(row & 63, dch));
-      const bf16x8 o8 = __builtin_bit_cast(bf16x8, og[it]), l8 = __builtin_bit_cast(bf16x8, ol[it]);
-      float d_ = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(dv[e]);
-      d_ = sum_lanes_cpr<CPR>(d_);
-      if (dch == 0) {
-        del_s[row] = row < T ? d_ : 0.f;
-        lse_s[row] = row < T ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
-        rk_s[row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
-        if (row < T) p.delta[(long)bh * T + row] = d_;
-      }
-    }
-  }
-  __syncthreads();
-
-  const float c = p.scale * LOG2E;
-  const int nq = R >> 4, npairs = (nq + 1) >> 1, nks = (T + 31) >> 5;
-  f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16], csq[DPW];
-#pragma unroll
-  for (int i = 0; i < DPW; ++i) csq[i] = zero4();
-#pragma unroll
-  for (int i = 0; i < DH / 16; ++i) {
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
-  }
-
-  for (int half = 0; half < 2; ++half) {
-    const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
-    if (pp0 >= npairs) break;  // uniform over the workgroup
-    // ------------------------------------------------------------------ phase A: this wave's keys x the half's queries
-    if (k00 < R && !(VIT_ATTN_SKIP & 2)) {
-      for (int pp = pp0; pp < pp1; ++pp) {
-        const int qb0 = pp * 32;
-        const char* Qt = Qimg + (qb0 >> 6) * TILE;
-        const char* Ot = Oimg + (qb0 >> 6) * TILE;
-        const int u32 = qb0 & 32;  // row offset of the pair inside its 64-row tile
-        u32x2 pdh[RQ][2], dsh[RQ][2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int q0 = qb0 + jj * 16;
-#pragma unroll
-          for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
-          if (q0 < R) {
-            f32x4 s_[RQ], dp[RQ];
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
-#pragma unroll
-            for (int s = 0; s < DH / 32; ++s) {
-              const bf16x8 qfr = frag_rows<DH>(Qt, u32 + jj * 16, s, l15, lg);
-              const bf16x8 ofr = frag_rows<DH>(Ot, u32 + jj * 16, s, l15, lg);
-#pragma unroll
-              for (int rq = 0; rq < RQ; ++rq) {
-                s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
-                dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
-              }
-            }
-            const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
-            const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
-            const u32x4 rk4 = *(const u32x4*)(rk_s + q0 + lg * 4);
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-              const unsigned key = k00 + rq * 16 + l15;
-              float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-              if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float pr = fast_exp2(s_[rq][r] * c - l4[r]);  // rows past T carry lse = +inf -> 0
-                pdv[r] = pr * mk[r];
-                dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
-              }
-              pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
-              dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
-              if (k00 + rq * 16 < R)  // [key][query of the half]: 4 consecutive queries of this lane's key
-                *(u32x2*)(dSimg + ds_off(k00 + rq * 16 + l15, ((q0 - pp0 * 32) >> 2) + lg)) = dsh[rq][jj];
-            }
-          }
-        }
-        bf16x8 pf[RQ], df[RQ];
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-          pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
-          df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
-        }
-        const int rb1 = (qb0 + 16 < R) ? u32 + 16 : u32;  // an un-staged block: its P and dS are 0
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) {
-          const bf16x8 otf = frag_cols<DH>(Ot, u32, rb1, dt * 16, l15, lg);
-          const bf16x8 qtf = frag_cols<DH>(Qt, u32, rb1, dt * 16, l15, lg);
-#pragma unroll
-          for (int rq = 0; rq < RQ; ++rq) {
-            dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
-            dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ------------------------------------------------------------------ phase B: dQ of query tile (2 pp0 + wave) over all keys
-    const int qt = pp0 * 2 + wave / WPQ, dt0 = (wave % WPQ) * DPW;
-    if (qt < nq && qt < pp1 * 2 && !(VIT_ATTN_SKIP & 1)) {
-      f32x4 dqt[DPW];
-#pragma unroll
-      for (int i = 0; i < DPW; ++i) dqt[i] = zero4();
-      const int tq = l15 >> 2, tp = l15 & 3;
-      // keys kb + 4 lg + tq (+ 16): the swizzle term depends on key & 15 only, so it is one constant per lane
-      const char* dcol = dSimg + ds_off(4 * lg + tq, (wave / WPQ) * 4 + tp);
-      for (int ks = 0; ks < nks; ++ks) {
-        const int kb = ks * 32;
-        const bool hi_ok = kb + 16 < R;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + kb * DSP));
-        bf16x4 hi = {0, 0, 0, 0};
-        if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16) * DSP));
-        const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const char* Kt = Kimg + (kb >> 6) * TILE;
-        const int r0 = kb & 63;
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-          const bf16x8 ktf = frag_cols<DH>(Kt, r0, hi_ok ? r0 + 16 : r0, (dt0 + i) * 16, l15, lg);
-          dqt[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[i], 0, 0, 0);
-        }
-      }
-      const int q = qt * 16 + l15;
-      if (q < T) {
-        short* o = p.dqkv + ((long)b * T + q) * ld + h * dh;
-#pragma unroll
-        for (int i = 0; i < DPW; ++i) {
-          const int d = (dt0 + i) * 16 + lg * 4;
-          if (d < dh) {
-            const f32x4 v = dqt[i] * p.scale;
-            u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            *(u32x2*)(o + d) = pk;
-            csq[i] += bf_round4(pk);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  const int dt0_ = (wave % WPQ) * DPW;
-  // ---- dK, dV of this wave's keys; per-wave column sums of everything this wave stored (the QKV bias gradient)
-  f32x4 csk[DH / 16], csv[DH / 16];
-#pragma unroll
-  for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
-#pragma unroll
-  for (int rq = 0; rq < RQ; ++rq) {
-    const int key = k00 + rq * 16 + l15;
-    if (key < T && !(VIT_ATTN_SKIP & 8)) {
-      short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * dh + h * dh;
-      short* ov = ok + p.H * dh;
-#pragma unroll
-      for (int dt = 0; dt < DH / 16; ++dt) {
-        const int d = dt * 16 + lg * 4;
-        if (d < dh) {
-          const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
-          u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
-          u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          *(u32x2*)(ok + d) = pk;
-          *(u32x2*)(ov + d) = pv;
-          csk[dt] += bf_round4(pk);
-          csv[dt] += bf_round4(pv);
-        }
-      }
-    }
-  }
-  if (p.csum_part) {
-    float* csum = p.csum_part + ((long)b * NW + wave) * ld + h * dh;
-#pragma unroll
-    for (int dt = 0; dt < DH / 16; ++dt) {
-      const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
-      f32x4 tq_ = zero4();  // this wave summed dQ only over its own d-tiles [dt0, dt0 + DPW)
-#pragma unroll
-      for (int i = 0; i < DPW; ++i)
-        if (dt == dt0_ + i) tq_ = rows16_sum(csq[i]);
-      const int d = dt * 16 + lg * 4;
-      if (l15 == 0 && d < dh) {
-        *(f32x4*)(csum + d) = tq_;
-        *(f32x4*)(csum + p.H * dh + d) = tk;
-        *(f32x4*)(csum + 2 * p.H * dh + d) = tv;
-      }
-    }
-  }
-}
-
-// ======================================================================================= persistent fused backward
-// The fused kernel above spends about half of its time outside the two compute phases: one workgroup per CU means the
-// global loads of a head, its compute and its stores run one after the other, and every head pays a workgroup launch.
-// This form keeps ONE workgroup per CU alive over its share of the heads and pipelines across (head, half) units:
-//   * Q / dO arrive by LDS-DMA (global_load_lds, no registers) one unit ahead, into the other of two 32 KiB buffers that
-//     each hold the 128 query rows of a half (the DMA writes 1 KiB of consecutive LDS per wave-instruction, so the XOR
-//     swizzle of the image is applied to the GLOBAL address of each lane);
-//   * the next head's K image is issued as soon as phase B of the current head has released it and lands during the next
-//     phase A; the next head's K / V rows (registers, dead outside phase A) and the O / O_lo / dO chunks of its delta
-//     pre-pass are issued before the last phase B and consumed after it.
-// Rows past T are clamped to row T - 1 instead of zero-filled (a DMA has no bounds check): their probabilities are 0 through
-// lse = +inf (queries) or a -inf added to the exponent (keys), so nothing depends on what the duplicate rows hold.
-// dh == 64 only (ViT-B / ViT-L); T <= 224 (LDS: 64 KiB of Q / dO buffers + K + a 128-query dS image + statistics).
-__global__ __launch_bounds__(512) void attn_bwd_persist_kernel(AttnArgs p) {
-  resolve_drop(p.drop);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int DH = 64, NW = 8, TILE = RT * DH * 2, HALFB = 128 * DH * 2, RQ = 2, CPR = 8;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int T = p.T, BH = p.B * p.H;
-  const long ld = 3L * p.H * DH, ldc = (long)p.H * DH;
-  const int R = (T + 15) & ~15;
-  const int nq = R >> 4, npairs = (nq + 1) >> 1, nks = (T + 31) >> 5, nhalves = npairs > 4 ? 2 : 1;
-  char* QD = smem;                      // two buffers of [Q half | dO half]
-  char* Kimg = smem + 4 * HALFB;
-  char* dSimg = Kimg + R * (DH * 2);
-  float* stats = (float*)(dSimg + R * DSP);  // two sets of [lse | delta | dropout row key], R words each: heads alternate
-  const float c = p.scale * LOG2E;
-  const int k00 = wave * RQ * 16;
-  const int dch = lane % CPR;
-
-  bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
-
-  const long HD = (long)p.H * DH;
-  auto qoff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ld + (long)(bh - b * p.H) * DH; };
-  auto coff_of = [&](int bh) -> long { const int b = bh / p.H; return (long)b * T * ldc + (long)(bh - b * p.H) * DH; };
-  auto issue_half = [&](char* buf, int bh, int half) {
-    if (!(VIT_ATTN_SKIP & 4)) {
-      dma_rows64(buf, p.qkv + qoff_of(bh), ld, half * 128, 128, T, wave, lane);
-      dma_rows64(buf + HALFB, p.dctx + coff_of(bh), ldc, half * 128, 128, T, wave, lane);
-    }
-  };
-  auto issue_k = [&](int bh) {
-    if (!(VIT_ATTN_SKIP & 4)) dma_rows64(Kimg, p.qkv + qoff_of(bh) + HD, ld, 0, R, T, wave, lane);
-  };
-  auto issue_regs = [&](int bh) {  // this wave's K / V rows of head bh
-    if (VIT_ATTN_SKIP & 16) return;
-    const short* kb_ = p.qkv + qoff_of(bh) + HD;
-#pragma unroll
-    for (int rq = 0; rq < RQ; ++rq) {
-      load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, DH, l15, lg);
-      load_own<DH>(vf[rq], kb_ + HD, ld, k00 + rq * 16, T, DH, l15, lg);
-    }
-  };
-  // delta[q] = sum_d dO (O + O_lo) and lse (exp2 domain) of head bh into statistics set `st`, rows row0, row0 + step, ...
-  // (8 lanes per row).  The first head: all waves; every later head: wave 7 alone, which owns no keys at T <= 224 and
-  // would otherwise idle through phase A -- it works one head ahead into the other statistics set.
-  // delta[q] = sum_d dO (O + O_lo) and lse (exp2 domain) of head bh, rows [row_lo, row_hi) (at most 128: two 8-row groups per
-  // wave), into statistics set `st`.  Split in two so the loads can be issued before a phase B and consumed after it.
-  i32x4 o4[2], d4[2], l4[2];
-  auto delta_issue = [&](int bh, int row_lo, int row_hi) {
-    const long co = coff_of(bh);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
-      o4[i] = d4[i] = l4[i] = (i32x4){0, 0, 0, 0};
-      if (row < T && row < row_hi && !(VIT_ATTN_SKIP & 16)) {
-        const long e0 = co + (long)row * ldc + dch * 8;
-        o4[i] = *(const i32x4*)(p.ctx + e0);
-        d4[i] = *(const i32x4*)(p.dctx + e0);
-        if (p.ctx_lo) l4[i] = *(const i32x4*)(p.ctx_lo + e0);
-      }
-    }
-  };
-  auto delta_finish = [&](int bh, float* st, int row_lo, int row_hi) {
-    // lse of the two rows first: issued while the chunk loads are still in flight, not after the reduction (that was one
-    // more exposed round trip per unit)
-    float lsev[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
-      lsev[i] = (row < T && row < row_hi && !(VIT_ATTN_SKIP & 32)) ? p.lse[(long)bh * T + row] * LOG2E : INFINITY;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = row_lo + (i * NW + wave) * 8 + (lane >> 3);
-      const bf16x8 o8 = __builtin_bit_cast(bf16x8, o4[i]), d8 = __builtin_bit_cast(bf16x8, d4[i]);
-      const bf16x8 l8 = __builtin_bit_cast(bf16x8, l4[i]);
-      float d_ = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d_ += (bf2f(o8[e]) + bf2f(l8[e])) * bf2f(d8[e]);
-      d_ = sum_lanes_cpr<CPR>(d_);
-      if (dch == 0 && row < row_hi && row < R) {
-        st[R + row] = row < T ? d_ : 0.f;
-        st[row] = lsev[i];
-        ((unsigned*)st)[2 * R + row] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + row) : 0u;
-        if (row < T && !(VIT_ATTN_SKIP & 32)) p.delta[(long)bh * T + row] = d_;
-      }
-    }
-  };
-
-  int bh = blockIdx.x;
-  if (bh >= BH) return;
-  // ---- prologue: first unit's operands, first head's K image, registers and statistics
-  issue_half(QD, bh, 0);
-  issue_k(bh);
-  issue_regs(bh);
-  for (int r0 = 0; r0 < R; r0 += 128) {
-    delta_issue(bh, r0, min(R, r0 + 128));
-    delta_finish(bh, stats, r0, min(R, r0 + 128));
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int u = 0, hidx = 0;
-  for (; bh < BH; bh += gridDim.x, ++hidx) {
-    const int bh_next = bh + gridDim.x;
-    const float* lse_s = stats + (hidx & 1) * (3 * R);
-    const float* del_s = lse_s + R;
-    const unsigned* rk_s = (const unsigned*)(del_s + R);
-    const int b = bh / p.H, h = bh - b * p.H;
-    f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
-#pragma unroll
-    for (int i = 0; i < DH / 16; ++i)
-#pragma unroll
-      for (int rq = 0; rq < RQ; ++rq) dkt[rq][i] = dvt[rq][i] = zero4();
-    // two partial rows per wave (one per half of the queries): no read-modify-write of a partial through global memory
-    float* csum = p.csum_part ? p.csum_part + ((long)b * NW + wave) * 2 * ld + h * DH : nullptr;
-    for (int half = 0; half < nhalves; ++half, ++u) {
-      char* cur = QD + (u & 1) * (2 * HALFB);
-      char* nxt = QD + ((u + 1) & 1) * (2 * HALFB);
-      const bool last_half = half + 1 == nhalves;
-      auto prefetch_next = [&]() {
-        if (!last_half) issue_half(nxt, bh, half + 1);
-        else if (bh_next < BH) issue_half(nxt, bh_next, 0);
-      };
-      const int pp0 = half * 4, pp1 = min(pp0 + 4, npairs);
-      // The prefetch is issued AFTER the first query pair of phase A (or here, by a wave that has no phase A): the first MFMA of
-      // phase A needs the K / V rows that came by global loads, for which the compiler can only write s_waitcnt vmcnt(0) --
-      // with the LDS-DMA already in flight that wait drained the prefetch it was meant to overlap (369 -> 362 us).
-      const bool in_a = k00 < R && !(VIT_ATTN_SKIP & 2) && pp0 < pp1;
-      if (!in_a) prefetch_next();
-      // ------------------------------------------------------------------ phase A
-      if (k00 < R && !(VIT_ATTN_SKIP & 2)) {
-        const float kinf[RQ] = {(k00 + l15 < T) ? 0.f : INFINITY, (k00 + 16 + l15 < T) ? 0.f : INFINITY};
-        for (int pp = pp0; pp < pp1; ++pp) {
-          const int qb0 = pp * 32, ql = (pp - pp0) * 32;  // global / buffer-local first query row of the pair
-          const char* Qt = cur + (ql >> 6) * TILE;
-          const char* Ot = cur + HALFB + (ql >> 6) * TILE;
-          const int u32 = ql & 32;
-          u32x2 pdh[RQ][2], dsh[RQ][2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int q0 = qb0 + jj * 16;
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) pdh[rq][jj] = dsh[rq][jj] = (u32x2){0u, 0u};
-            if (q0 < R) {
-              f32x4 s_[RQ], dp[RQ];
-#pragma unroll
-              for (int rq = 0; rq < RQ; ++rq) s_[rq] = dp[rq] = zero4();
-#pragma unroll
-              for (int s = 0; s < DH / 32; ++s) {
-                const bf16x8 qfr = frag_rows<DH>(Qt, u32 + jj * 16, s, l15, lg);
-                const bf16x8 ofr = frag_rows<DH>(Ot, u32 + jj * 16, s, l15, lg);
-#pragma unroll
-                for (int rq = 0; rq < RQ; ++rq) {
-                  s_[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[rq][s], s_[rq], 0, 0, 0);
-                  dp[rq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[rq][s], dp[rq], 0, 0, 0);
-                }
-              }
-              const f32x4 l4 = *(const f32x4*)(lse_s + q0 + lg * 4);
-              const f32x4 d4 = *(const f32x4*)(del_s + q0 + lg * 4);
-              const u32x4 rk4 = *(const u32x4*)(rk_s + q0 + lg * 4);
-#pragma unroll
-              for (int rq = 0; rq < RQ; ++rq) {
-                const unsigned key = k00 + rq * 16 + l15;
-                float pdv[4], dsv[4], mk[4] = {1.f, 1.f, 1.f, 1.f};
-                if (p.drop.thr) drop_mask4_keyowner(p.drop, rk4, key, l15, mk);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  // queries past T carry lse = +inf, keys past T add +inf: probability 0 either way
-                  const float pr = fast_exp2(s_[rq][r] * c - (l4[r] + kinf[rq]));
-                  pdv[r] = pr * mk[r];
-                  dsv[r] = pr * (dp[rq][r] * mk[r] - d4[r]);
-                }
-                pdh[rq][jj] = (u32x2){pack2bf(pdv[0], pdv[1]), pack2bf(pdv[2], pdv[3])};
-                dsh[rq][jj] = (u32x2){pack2bf(dsv[0], dsv[1]), pack2bf(dsv[2], dsv[3])};
-                if (k00 + rq * 16 < R)
-                  *(u32x2*)(dSimg + ds_off(k00 + rq * 16 + l15, (ql >> 2) + jj * 4 + lg)) = dsh[rq][jj];
-              }
-            }
-          }
-          bf16x8 pf[RQ], df[RQ];
-#pragma unroll
-          for (int rq = 0; rq < RQ; ++rq) {
-            pf[rq] = __builtin_bit_cast(bf16x8, (u32x4){pdh[rq][0][0], pdh[rq][0][1], pdh[rq][1][0], pdh[rq][1][1]});
-            df[rq] = __builtin_bit_cast(bf16x8, (u32x4){dsh[rq][0][0], dsh[rq][0][1], dsh[rq][1][0], dsh[rq][1][1]});
-          }
-#pragma unroll
-          for (int dt = 0; dt < DH / 16; ++dt) {
-            const bf16x8 otf = frag_cols<DH>(Ot, u32, u32 + 16, dt * 16, l15, lg);
-            const bf16x8 qtf = frag_cols<DH>(Qt, u32, u32 + 16, dt * 16, l15, lg);
-#pragma unroll
-            for (int rq = 0; rq < RQ; ++rq) {
-              dvt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[rq], dvt[rq][dt], 0, 0, 0);
-              dkt[rq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df[rq], dkt[rq][dt], 0, 0, 0);
-            }
-          }
-          if (pp == pp0) prefetch_next();  // after the first pair: the waits its register operands needed are behind us
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next unit's Q / dO (and a K image issued a unit ago) landed
-      __syncthreads();
-      if (last_half && bh_next < BH) issue_regs(bh_next);  // K / V rows are dead until the next head's phase A
-      // the next head's statistics, this half's share of the rows: loads now, arithmetic after phase B, into the other set
-      const int drow_lo = half * 128, drow_hi = min(R, drow_lo + 128);
-      if (bh_next < BH) delta_issue(bh_next, drow_lo, drow_hi);
-      // ------------------------------------------------------------------ phase B: dQ of query tile (2 pp0 + wave)
-      const int qt = pp0 * 2 + wave;
-      {
-        f32x4 dqt[DH / 16];
-#pragma unroll
-        for (int i = 0; i < DH / 16; ++i) dqt[i] = zero4();
-        const bool have = qt < nq && qt < pp1 * 2 && !(VIT_ATTN_SKIP & 1);
-        if (have) {
-          const int tq = l15 >> 2, tp = l15 & 3;
-          const char* dcol = dSimg + ds_off(4 * lg + tq, wave * 4 + tp);
-          for (int ks = 0; ks < nks; ++ks) {
-            const int kb = ks * 32;
-            const bool hi_ok = kb + 16 < R;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + kb * DSP));
-            bf16x4 hi = {0, 0, 0, 0};
-            if (hi_ok) hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS bf16x4*)(dcol + (kb + 16) * DSP));
-            const bf16x8 dsf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const char* Kt = Kimg + (kb >> 6) * TILE;
-            const int r0 = kb & 63;
-#pragma unroll
-            for (int dt = 0; dt < DH / 16; ++dt) {
-              const bf16x8 ktf = frag_cols<DH>(Kt, r0, hi_ok ? r0 + 16 : r0, dt * 16, l15, lg);
-              dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[dt], 0, 0, 0);
-            }
-          }
-        }
-        const int q = qt * 16 + l15;
-        short* o = p.dqkv + ((long)b * T + q) * ld + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) {
-          const f32x4 v = dqt[dt] * p.scale;
-          u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-          if (have && q < T) *(u32x2*)(o + dt * 16 + lg * 4) = pk;
-          else pk = (u32x2){0u, 0u};
-          if (csum) {  // this wave's dQ column sums of this half: partial row `half`
-            const f32x4 t = rows16_sum(bf_round4(pk));
-            if (l15 == 0) *(f32x4*)(csum + half * ld + dt * 16 + lg * 4) = t;
-          }
-        }
-      }
-      if (last_half) {  // dK, dV of this wave's keys and the column sums of everything this wave stored for the head
-        f32x4 csk[DH / 16], csv[DH / 16];
-#pragma unroll
-        for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
-#pragma unroll
-        for (int rq = 0; rq < RQ; ++rq) {
-          const int key = k00 + rq * 16 + l15;
-          if (key < T && !(VIT_ATTN_SKIP & 8)) {
-            short* ok = p.dqkv + ((long)b * T + key) * ld + p.H * DH + h * DH;
-            short* ov = ok + p.H * DH;
-#pragma unroll
-            for (int dt = 0; dt < DH / 16; ++dt) {
-              const int d = dt * 16 + lg * 4;
-              const f32x4 a = dkt[rq][dt] * p.scale, v = dvt[rq][dt];
-              u32x2 pk = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
-              u32x2 pv = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-              *(u32x2*)(ok + d) = pk;
-              *(u32x2*)(ov + d) = pv;
-              csk[dt] += bf_round4(pk);
-              csv[dt] += bf_round4(pv);
-            }
-          }
-        }
-        if (csum) {  // key / value thirds: row 0 carries the sums, row 1 zeros (and a zero query third when there is one half)
-#pragma unroll
-          for (int dt = 0; dt < DH / 16; ++dt) {
-            const f32x4 tk = rows16_sum(csk[dt]), tv = rows16_sum(csv[dt]);
-            const int d = dt * 16 + lg * 4;
-            if (l15 == 0) {
-              *(f32x4*)(csum + HD + d) = tk;
-              *(f32x4*)(csum + 2 * HD + d) = tv;
-              *(f32x4*)(csum + ld + HD + d) = zero4();
-              *(f32x4*)(csum + ld + 2 * HD + d) = zero4();
-              if (nhalves == 1) *(f32x4*)(csum + ld + d) = zero4();
-            }
-          }
-        }
-      }
-      if (bh_next < BH) delta_finish(bh_next, stats + ((hidx + 1) & 1) * (3 * R), drow_lo, drow_hi);
-      __syncthreads();  // dS and (after the last half) the K image are free; the next head's statistics are visible
-      if (last_half && bh_next < BH) issue_k(bh_next);  // lands during the next head's first phase A
-    }
-  }
-}
-
 // ======================================================================================= pipelined fused backward (r03)
-// The persistent kernel above still ran its pieces one after the other: per (head, half) a phase A, a barrier, global loads
-// for the next head (K / V rows into registers, the O / O_lo / dO chunks and lse of the delta pre-pass), a phase B far too
-// short to cover them, another barrier -- 140 of its 364 us were that exposed chain (one workgroup per CU: nothing else
-// runs meanwhile), on top of 134 us of phase A that is VALU-bound.  This form removes every global -> register load and
-// every phase boundary from the critical path: the unit of work is a PAIR of query tiles (32 rows), one barrier per pair,
+// The single-kernel backward (one pass, dS through the LDS, five products instead of the two-kernel path's seven).  Its two
+// predecessors -- attn_bwd_fused_kernel<DH, NW> (one workgroup per head, r02) and attn_bwd_persist_kernel (one workgroup per CU
+// walking heads, r02) -- ran their pieces one after the other: per (head, half) a phase A, a barrier, global loads for the next
+// head, a phase B far too short to cover them, another barrier (140 of the persistent form's 364 us were that exposed chain).
+// They were removed in r04 once this form had carried the benchmarked shape for a round: what they still served (dh 64 with
+// T < 64 or 209 .. 240, dh 32) now takes the two-kernel resident path, which every test also covers.  This form removes every
+// global -> register load and every phase boundary from the critical path: the unit of work is a PAIR of query tiles (32 rows), one barrier per pair,
 // and in each barrier interval every stage of the backward runs for a DIFFERENT pair, on different waves:
 //
 //   iteration g:  top      B(g-1)   waves 4-7: dQ of pair g-1 (wave 4 + j: query tile j >> 1, 16-column tiles 2 (j & 1), + 1)
@@ -2320,20 +1729,10 @@ namespace vit {
 
 static bool pipe_fits(int T, int dh) { return dh == 64 && T >= 64 && T <= 208 && pipe_smem(T) <= 160 * 1024; }
 
-static bool persist_fits(int T, int dh) {
-  const size_t rows = (T + 15) & ~15;
-  return dh == 64 && T <= 224 && 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24) <= 160 * 1024;
-}
-
-// vit_set_option("attn_bwd_fused"): 0 = two-kernel backward, 1 / 2 = fused (8 / 16 waves), 3 = persistent form where it fits
-// (dh 64, T <= 224), 4 (default) = the pair-pipelined form where it fits (dh 64, 64 <= T <= 208), else 3, else 1
+// vit_set_option("attn_bwd_fused"): 0 = two-kernel backward everywhere; non-zero (default 4; 1 .. 3 named forms that no longer
+// exist and mean the same) = the pair-pipelined single kernel where it fits (dh 64, 64 <= T <= 208), the two-kernel path elsewhere
 int g_attn_bwd_fused = 4;
 int g_attn_fwd_waves = 12;  // vit_set_option("attn_fwd_waves"): most waves per workgroup of the resident forward (8 or 12)
-
-static bool fused_fits(int T, int dh) {
-  const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
-  return T <= 240 && rows * (3 * dhp * 2 + DSP + 12) <= 160 * 1024;
-}
 
 // resident kernels: a (batch, head)'s whole K/V (or Q/dO) in the LDS -- at head_dim 64 up to T = 592 rows (2 x 74 KiB; the
 // backward adds 4.6 KiB of row statistics): ViT-L/16 384^2 (T = 577) fits, one workgroup per CU, three workgroups of 7
@@ -2342,7 +1741,6 @@ constexpr int RES_MAX_T = 592, RES_MAX_DH = 64, RES_RQ = 2;
 int g_attn_res_max_t = RES_MAX_T;  // vit_set_option("attn_res_max_t"): larger T goes to the tiled kernels
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
 
-static bool persist_fits(int T, int dh);
 static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + two f32 rows of statistics
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
   return 2 * rows * dhp * 2 + 3 * rows * 4 <= 160 * 1024;
@@ -2950,11 +2348,8 @@ int vit_attention_bwd_lo(vit_handle h, const void* qkv, const void* ctx, const v
     res_geometry(T, &nsplit, &wpw);
     size_t wsb = 0;
     float* part = (float*)ctx_workspace(h, &wsb);
-    const bool fused = g_attn_bwd_fused && fused_fits(T, dh);  // partial rows per batch: one per wave (8 / 16 waves), or in
-    // the persistent form two per wave (one per half of the queries)
-    const bool pipe = g_attn_bwd_fused >= 4 && pipe_fits(T, dh);
-    const bool persist = !pipe && g_attn_bwd_fused >= 3 && persist_fits(T, dh);
-    const int prow = fused ? B * (pipe ? 8 : (persist || g_attn_bwd_fused == 2 ? 16 : 8)) : B * nsplit * wpw;
+    const bool pipe = g_attn_bwd_fused && pipe_fits(T, dh);  // partial rows per batch: one per wave of the pipelined kernel
+    const int prow = pipe ? B * 8 : B * nsplit * wpw;
     if (part && wsb >= (size_t)prow * D3 * sizeof(float)) {
       // the resident kernels leave one partial row per wave: column sums of what they stored
       int rc = attention_bwd_impl(h, qkv, ctx, ctx_lo, dctx, lse, delta, dqkv, io_dtype, B, H, T, dh, scale, dropout_p, seed,
@@ -2993,50 +2388,19 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
   a.B = B; a.H = H; a.T = T; a.dh = dh; a.scale = scale;
   a.drop = make_drop_h(h, dropout_p, seed, site);
   a.csum_part = colsum_part;
-  if (g_attn_bwd_fused && T <= g_attn_res_max_t && dh <= RES_MAX_DH && (dh % 4) == 0 && fused_fits(T, dh)) {
-    const size_t rows = (T + 15) & ~15;
-    const size_t smem = rows * (3 * (dh <= 32 ? 32 : 64) * 2 + DSP + 12);
-    if (g_attn_bwd_fused >= 4 && pipe_fits(T, dh)) {
-      static bool attr = false;
-      if (!attr) {
-        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-      }
-      const dim3 grid(std::min(B * H, ctx_num_cus(h)));
-      if (T > 192 && H == 12 && a.ctx_lo)  // the ViT-B shape: everything the padded length and the head count determine is constant
-        hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 12, true>), grid, dim3(512), pipe_smem(T), st, a);
-      else if (T > 192) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
-      else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
-      VIT_LAUNCH_CHECK();
-      return VIT_OK;
+  if (g_attn_bwd_fused && T <= g_attn_res_max_t && pipe_fits(T, dh)) {
+    static bool attr = false;
+    if (!attr) {
+      VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_pipe_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
     }
-    if (g_attn_bwd_fused >= 3 && persist_fits(T, dh)) {
-      static bool attr = false;
-      if (!attr) {
-        VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-      }
-      const size_t sm = 4 * 128 * 64 * 2 + rows * (64 * 2 + DSP + 24);
-      hipLaunchKernelGGL(attn_bwd_persist_kernel, dim3(std::min(B * H, ctx_num_cus(h))), dim3(512), sm, st, a);
-      VIT_LAUNCH_CHECK();
-      return VIT_OK;
-    }
-    const int nw = g_attn_bwd_fused == 2 ? 16 : 8;  // 3 / 4 that did not fit their forms: the 8-wave fused kernel
-#define LAUNCH_FUSED(DH_, NW_)                                                                                           \
-  do {                                                                                                                   \
-    static bool attr = false;                                                                                            \
-    if (!attr) {                                                                                                         \
-      VIT_HIP(hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<DH_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  160 * 1024));                                                                          \
-      attr = true;                                                                                                       \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<DH_, NW_>), dim3(B * H), dim3(NW_ * 64), smem, st, a);                    \
-  } while (0)
-    if (dh <= 32) { if (nw == 16) LAUNCH_FUSED(32, 16); else LAUNCH_FUSED(32, 8); }
-    else { if (nw == 16) LAUNCH_FUSED(64, 16); else LAUNCH_FUSED(64, 8); }
-#undef LAUNCH_FUSED
+    const dim3 grid(std::min(B * H, ctx_num_cus(h)));
+    if (T > 192 && H == 12 && a.ctx_lo)  // the ViT-B shape: everything the padded length and the head count determine is constant
+      hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 12, true>), grid, dim3(512), pipe_smem(T), st, a);
+    else if (T > 192) hipLaunchKernelGGL((attn_bwd_pipe_kernel<true, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
+    else hipLaunchKernelGGL((attn_bwd_pipe_kernel<false, 0, false>), grid, dim3(512), pipe_smem(T), st, a);
     VIT_LAUNCH_CHECK();
     return VIT_OK;
   }
