@@ -196,9 +196,11 @@ def main():
                          "Measured equal to eager launches within noise (the host runs ahead of the GPU either way) and 0.7 ms "
                          "slower when combined with the second stream, so it is opt-in and switches the second stream off")
     ap.add_argument("--no-graph", action="store_true", help="(default now; kept so older command lines still parse)")
-    ap.add_argument("--reserve-cus", type=int, default=0,
+    ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="size the one-workgroup-per-CU kernels for this many fewer CUs (room for the collective's kernels when "
-                         "the gradient exchange overlaps the backward; 0 = all CUs)")
+                         "the gradient exchange overlaps the backward; 0 = all CUs).  Default -1: 0 on one GPU; with N > 1 the "
+                         "value is chosen BEFORE the warm-up by timing three steps at 0 / 8 / 16 / 32 (Trainer.autotune_reserve_cus; "
+                         "no multi-GPU run of this path has been measured yet, so the first one tunes itself) and reported")
     ap.add_argument("--no-gc-freeze", action="store_true",
                     help="diagnostic: leave the start-up heap in the cyclic GC's young generations (shows the pause the freeze removes)")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
@@ -249,6 +251,9 @@ def main():
         "data": {"param": "log_g"},
         "noise": {"noise_level": 0},
     }
+    autotune = args.reserve_cus < 0 and exchanging
+    if args.reserve_cus < 0:
+        args.reserve_cus = 0
     if args.reserve_cus:
         _cabi.set_option("reserve_cus", args.reserve_cus)
     seed_everything(42)  # scripts/run.py:22,28
@@ -294,6 +299,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    tuned = None
+    if autotune:
+        tuned = trainer.autotune_reserve_cus(module, batch)
+        args.reserve_cus = trainer.reserve_cus
+        if rank == 0:
+            log(f"reserve_cus autotune (ms per step): {tuned} -> {args.reserve_cus}")
     if rank == 0:
         log(f"model on {dev}, {sum(p.numel() for p in module.parameters())} parameters; warm-up {args.warmup} steps")
     for i in range(args.warmup):
@@ -392,7 +403,9 @@ def main():
         eng = module.model.engine
         red = trainer.reducer
         comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "exchange": red.mode,
-                "collectives_per_step": red.calls_per_step, "bytes_per_step": red.bytes_per_step}
+                "collectives_per_step": red.calls_per_step, "bytes_per_step": red.bytes_per_step,
+                "reserve_cus": args.reserve_cus,
+                "reserve_cus_autotune_ms": {str(k): round(v, 3) for k, v in tuned.items()} if tuned else None}
         if not args.no_comm_probe:
             try:
                 comm.update(comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, median_ms))

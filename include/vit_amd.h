@@ -55,6 +55,9 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "attn_bwd_fused": attention backward form: non-zero (default 4) = the pair-pipelined single kernel where it fits (head_dim
  *                64, 64 <= T <= 208), the dQ + dK/dV pair elsewhere; 0 = the dQ + dK/dV pair everywhere.  (The values 1 .. 3
  *                named the single-kernel forms of round 2, removed in round 4; they are accepted and mean the default.)
+ *   "attn_bwd_dma": 1 (default) = the dQ + dK/dV pair at head_dim 64 stages its LDS images by LDS-DMA in reading order with
+ *                per-tile counted waits (the first tile's arithmetic starts when 16 KiB have landed); 0 = register-staged
+ *                images, all in before the loop starts.  Same results bit for bit.
  *   "attn32_mfma": 1 (default) = fp32 attention (precision '32') at head_dim 64 runs on the f32-input matrix instructions
  *                (v_mfma_f32_16x16x4_f32: exact f32 products and accumulation); 0 = the one-wave-per-row vector kernels.
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.

@@ -131,3 +131,36 @@ def test_untracked_q_loads_are_not_read_before_their_wait(kernel_isa):
             if not l or l.startswith(";") or l.startswith(".") or "global_load_lds" in l:
                 continue
             assert not (regs(l) & dst), (name, i, l)
+
+
+def test_untracked_own_row_loads_of_the_resident_backward(kernel_isa):
+    """The DMA forms of the two resident backward kernels (r04: images requested in reading order, per-tile counted waits) read the
+    wave's own rows -- Q / dO / O / O_lo / lse, or K / V -- with inline-asm loads the compiler does not track, the oldest operations
+    in the vmcnt order.  Between each of those loads and the first counted wait nothing may read, copy or overwrite its
+    destination registers (the data has not landed): checked on the emitted ISA, as for the forward's Q loads."""
+    import re
+
+    text = kernel_isa["attention"]
+
+    def regs(line):
+        r = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", line):
+            r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", line):
+            r.add(int(m.group(1)))
+        return r
+
+    kernels = list(_kernel_bodies(text, r"_ZN3vit2[23]attn_bwd_d(?:q|kv)_res_kernelILi64ELi2ELb1E\w+"))
+    assert len(kernels) == 2, [k for k, _ in kernels]
+    for name, body in kernels:
+        loads = [i for i, l in enumerate(body) if l.startswith("global_load_dword") and "lds" not in l and body[i - 1].startswith(";;#ASMSTART")]
+        assert len(loads) in (8, 18), (name, len(loads))  # dK/dV: K, V rows; dQ: Q, dO, O, O_lo rows + lse
+        wait = next(i for i, l in enumerate(body) if i > loads[-1] and "s_waitcnt vmcnt" in l)
+        for li in loads:
+            dst = regs(body[li].split(",")[0])
+            for i in range(li + 1, wait):
+                l = body[i]
+                if not l or l.startswith(";") or l.startswith(".") or "global_load_lds" in l:
+                    continue
+                assert not (regs(l) & dst), (name, li, i, l)
+        assert not [l for l in body if "scratch_" in l], name

@@ -175,6 +175,8 @@ def test_bench_two_ranks_reports_the_multi_gpu_probe():
     assert abs(doc["value"] - 1024 / (doc["ms_per_step"] * 1e-3)) < 1e-2 * doc["value"]
     comm = doc["comm"]
     assert comm["backend"] == "gloo" and comm["world_size"] == 2 and "probe_error" not in comm, comm
+    assert sorted(comm["reserve_cus_autotune_ms"]) == ["0", "16", "32", "8"] and comm["reserve_cus"] in (0, 8, 16, 32)
+    assert doc["config"]["reserve_cus"] == comm["reserve_cus"]  # what the timed steps ran with
     assert [x["reserve_cus"] for x in comm["reserve_cus_sweep"]] == [0, 8, 16, 32]
     for x in comm["reserve_cus_sweep"]:
         assert x["ms_per_step"] > 0 and x["ms_per_step_exchange_off"] > 0

@@ -18,7 +18,7 @@ struct vit_ctx {
 namespace vit {
 
 extern int g_gemm2_mode, g_pp_slots, g_balance_wgs, g_half_tail, g_split_tail, g_grp2;  // gemm2.hip
-extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_fwd_waves, g_attn32_mfma;  // attention.hip
+extern int g_attn_split, g_attn_res_max_t, g_attn_bwd_fused, g_attn_fwd_waves, g_attn32_mfma, g_attn_bwd_dma;  // attention.hip
 
 static thread_local char g_err[512] = "";
 thread_local char g_last_gemm[96] = "";  // symbol of the kernel the last vit_gemm on this thread launched
@@ -111,6 +111,10 @@ int vit_set_option(const char* name, int value) {
   }
   if (strcmp(name, "attn_bwd_fused") == 0) {
     vit::g_attn_bwd_fused = value;
+    return VIT_OK;
+  }
+  if (strcmp(name, "attn_bwd_dma") == 0) {
+    vit::g_attn_bwd_dma = value ? 1 : 0;
     return VIT_OK;
   }
   if (strcmp(name, "reserve_cus") == 0) {

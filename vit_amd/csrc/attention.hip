@@ -528,7 +528,35 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {  // n is wave-uniform; a
     case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
   }
 }
 __device__ __forceinline__ void dma_rows64(char* img, const short* g, long ld, int row0, int nrows_img, int T, int wave,
@@ -879,14 +907,41 @@ __device__ __forceinline__ void drop_keep4_keyowner(const DropCfg& d, const u32x
   for (int r = 0; r < 4; ++r) keep[r] = (h[r] << sh) >= thr16;
 }
 
-template <int DH, int RQ>
+// The staged-image prologue of the two resident backward kernels, DMA form (dh == DH == 64).  One workgroup per CU at
+// T = 577 (148 KiB of images), six of them one after the other: the register-staged prologue (global -> registers -> LDS, two
+// or three full round trips for 148 KiB) sat in the open in front of each one's loop, ~6 of its ~35 us.  Here every piece
+// of the two images is requested up front by LDS-DMA IN THE ORDER THE LOOP READS THEM (tile 0 of both images, tile 1, ...),
+// the wave's own rows before them by loads the compiler does not track (it would wait vmcnt(0) at their first use and drain
+// the images with them), and the loop waits, tile by tile, with a COUNTED vmcnt for this wave's pieces of that tile and a
+// barrier that publishes everybody's: the first tile's arithmetic starts when 16 KiB have landed, the other 130 KiB arrive
+// underneath it.  Piece jg (8 rows x 128 B) of an image belongs to wave jg % nwaves; vmcnt retires in order, so "all but my
+// pieces of later tiles" is one number per tile.
+struct ImgDma {
+  int nwv, npc, wave, tot;
+  __device__ __forceinline__ int mine_below(int lim) const { return lim > wave ? (lim - wave + nwv - 1) / nwv : 0; }
+  // outstanding operations this wave may leave when tile kt (pieces < 8 (kt + 1)) is about to be read; PER = DMA instructions per piece
+  __device__ __forceinline__ int allowed(int kt, int per) const { return tot - per * mine_below(min(8 * (kt + 1), npc)); }
+};
+__device__ __forceinline__ void dma_piece64(unsigned img_a, const short* g, long ld, int jg, int T, int lane) {
+  const int r = (jg << 3) + (lane >> 3);
+  const int c = (lane & 7) ^ swz<64>(r & 63);
+  lds_dma16_s(g, __umul24((unsigned)min(r, T - 1), (unsigned)(ld * 2)) + (unsigned)(c * 16), img_a + jg * 1024);
+}
+__device__ __forceinline__ i32x4 load16_untracked(const short* src) {
+  i32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(src) : "memory");
+  return v;
+}
+
+template <int DH, int RQ, bool DMA = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
-  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const int T = p.T, dh = DMA ? DH : p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
   const short* kb_ = qb + p.H * dh;
@@ -898,44 +953,105 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   // share a CU's 160 KiB (whole 64-row tiles took 64 KiB: two)
   const int rows_alloc = (T + 15) & ~15;
   char* Vimg = smem + rows_alloc * (DH * 2);
-  load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
-  __syncthreads();
   const int q00 = (part * p.wpw + wave) * RQ * 16;
   float* csum = p.csum_part ? p.csum_part + ((long)(bh / p.H) * p.nsplit * p.wpw + part * p.wpw + wave) * ld + h * dh : nullptr;
-  if (q00 >= T) {
-    if (csum && lane < DH / 4 && lane * 4 < dh) *(f32x4*)(csum + lane * 4) = zero4();  // an idle wave's partial row
-    return;
-  }
+  const bool idle = q00 >= T;  // a wave with no query rows (the last workgroup of a head): DMA form, it still owes its pieces and barriers
 
   bf16x8 qf[RQ][DH / 32], dof[RQ][DH / 32];
   float lse2[RQ], del[RQ];
   f32x4 dqt[RQ][DH / 16];
+  ImgDma dm = {(int)(blockDim.x >> 6), rows_alloc >> 3, wave, 0};
+  if constexpr (DMA) {
+    i32x4 ov[RQ][DH / 32], lv[RQ][DH / 32];
+    float lraw[RQ];
+    const bool has_lo = p.ctx_lo != nullptr;
+    if (!idle) {
 #pragma unroll
-  for (int rq = 0; rq < RQ; ++rq) {
-    const int q = q00 + rq * 16 + l15;
-    load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
-    load_own<DH>(dof[rq], dob, ldc, q00 + rq * 16, T, dh, l15, lg);
-    lse2[rq] = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
-    float d_ = 0.f;
+      for (int rq = 0; rq < RQ; ++rq) {
+        const long row = min(q00 + rq * 16 + l15, T - 1);  // rows past T read the last row again (masked through lse = +inf)
 #pragma unroll
-    for (int s = 0; s < DH / 32; ++s) {
-      const int col = s * 32 + lg * 8;
-      if (q < T && col < dh) {
-        const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d_ += bf2f(o[e]) * bf2f(dof[rq][s][e]);
-        if (p.ctx_lo) {
-          const bf16x8 ol = *(const bf16x8*)(p.ctx_lo + (ob - p.ctx) + (long)q * ldc + col);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d_ += bf2f(ol[e]) * bf2f(dof[rq][s][e]);
+        for (int s = 0; s < DH / 32; ++s) {
+          const int col = s * 32 + lg * 8;
+          qf[rq][s] = __builtin_bit_cast(bf16x8, load16_untracked(qb + row * ld + col));
+          dof[rq][s] = __builtin_bit_cast(bf16x8, load16_untracked(dob + row * ldc + col));
+          ov[rq][s] = load16_untracked(ob + row * ldc + col);
+          if (has_lo) lv[rq][s] = load16_untracked(p.ctx_lo + (ob - p.ctx) + row * ldc + col);
         }
+        asm volatile("global_load_dword %0, %1, off" : "=v"(lraw[rq]) : "v"(p.lse + (long)bh * T + row) : "memory");
       }
     }
-    d_ = grp4_sum(d_);
-    if (q < T && lg == 0) p.delta[(long)bh * T + q] = d_;
-    del[rq] = d_;
+    const unsigned Ka = lds_addr_of(Kimg), Va = lds_addr_of(Vimg);
+    for (int jg = wave; jg < dm.npc; jg += dm.nwv) {  // ascending piece index = tile order
+      dma_piece64(Ka, kb_, ld, jg, T, lane);
+      dma_piece64(Va, vb, ld, jg, T, lane);
+      dm.tot += 2;
+    }
+    wait_vmcnt_dyn(dm.allowed(0, 2));  // my own rows (older than every piece) and my pieces of tile 0
+    __builtin_amdgcn_sched_barrier(0);
+    if (!idle) {
 #pragma unroll
-    for (int i = 0; i < DH / 16; ++i) dqt[rq][i] = zero4();
+      for (int rq = 0; rq < RQ; ++rq) {
+        asm volatile("" : "+v"(lraw[rq]));
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          asm volatile("" : "+v"(qf[rq][s]), "+v"(dof[rq][s]), "+v"(ov[rq][s]));  // their uses stay behind the wait
+          if (has_lo) asm volatile("" : "+v"(lv[rq][s]));
+        }
+        const int q = q00 + rq * 16 + l15;
+        lse2[rq] = q < T ? lraw[rq] * LOG2E : INFINITY;
+        float d_ = 0.f;
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          const bf16x8 o = __builtin_bit_cast(bf16x8, ov[rq][s]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d_ += bf2f(o[e]) * bf2f(dof[rq][s][e]);
+          if (has_lo) {
+            const bf16x8 ol = __builtin_bit_cast(bf16x8, lv[rq][s]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d_ += bf2f(ol[e]) * bf2f(dof[rq][s][e]);
+          }
+        }
+        d_ = grp4_sum(d_);
+        if (q < T && lg == 0) p.delta[(long)bh * T + q] = d_;
+        del[rq] = q < T ? d_ : 0.f;
+#pragma unroll
+        for (int i = 0; i < DH / 16; ++i) dqt[rq][i] = zero4();
+      }
+    }
+  } else {
+    load_all_tiles2<DH>(Kimg, kb_, ld, Vimg, vb, ld, T, dh, rows_alloc, tid, blockDim.x);
+    __syncthreads();
+    if (idle) {
+      if (csum && lane < DH / 4 && lane * 4 < dh) *(f32x4*)(csum + lane * 4) = zero4();  // an idle wave's partial row
+      return;
+    }
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+      const int q = q00 + rq * 16 + l15;
+      load_own<DH>(qf[rq], qb, ld, q00 + rq * 16, T, dh, l15, lg);
+      load_own<DH>(dof[rq], dob, ldc, q00 + rq * 16, T, dh, l15, lg);
+      lse2[rq] = q < T ? p.lse[(long)bh * T + q] * LOG2E : INFINITY;
+      float d_ = 0.f;
+#pragma unroll
+      for (int s = 0; s < DH / 32; ++s) {
+        const int col = s * 32 + lg * 8;
+        if (q < T && col < dh) {
+          const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d_ += bf2f(o[e]) * bf2f(dof[rq][s][e]);
+          if (p.ctx_lo) {
+            const bf16x8 ol = *(const bf16x8*)(p.ctx_lo + (ob - p.ctx) + (long)q * ldc + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d_ += bf2f(ol[e]) * bf2f(dof[rq][s][e]);
+          }
+        }
+      }
+      d_ = grp4_sum(d_);
+      if (q < T && lg == 0) p.delta[(long)bh * T + q] = d_;
+      del[rq] = d_;
+#pragma unroll
+      for (int i = 0; i < DH / 16; ++i) dqt[rq][i] = zero4();
+    }
   }
   const float c = p.scale * LOG2E;
   const unsigned half_cols = (unsigned)((T + 1) >> 1);
@@ -1008,11 +1124,38 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
       }
     }
   };
+  // DMA form: before a tile is read, this wave's pieces of it have landed (counted wait) and everybody's are published
+  // (barrier).  Three rendezvous only -- tile 0; tiles 1-2; everything else -- all while the waves are still in step anyway:
+  // a barrier in front of EVERY tile kept the seven waves in lock-step through the whole loop (all of them in their MFMA
+  // chains, then all in their exp / dropout arithmetic) and cost more than the prologue it hid (T = 577: 418 -> 434 us).
+  auto arrive = [&](int kt) {
+    if constexpr (DMA) {
+      if (kt == 0) {
+        __builtin_amdgcn_s_barrier();  // the wait for tile 0 was the prologue's
+      } else if (kt == 1) {
+        wait_vmcnt_dyn(dm.allowed(2, 2));
+        __builtin_amdgcn_s_barrier();
+      } else if (kt == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  };
   {
     using std::integral_constant;
     const int nfull = T / RT;
-    for (int kt = 0; kt < nfull; ++kt) tile(integral_constant<bool, false>{}, kt);
-    if (nfull * RT < T) tile(integral_constant<bool, true>{}, nfull);
+    for (int kt = 0; kt < nfull; ++kt) {
+      arrive(kt);
+      if (!DMA || !idle) tile(integral_constant<bool, false>{}, kt);
+    }
+    if (nfull * RT < T) {
+      arrive(nfull);
+      if (!DMA || !idle) tile(integral_constant<bool, true>{}, nfull);
+    }
+  }
+  if (DMA && idle) {
+    if (csum && lane < DH / 4) *(f32x4*)(csum + lane * 4) = zero4();  // an idle wave's partial row
+    return;
   }
   f32x4 cs[DH / 16];
 #pragma unroll
@@ -1044,59 +1187,117 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(AttnArgs p) {
   }
 }
 
-template <int DH, int RQ>
+template <int DH, int RQ, bool DMA = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
   resolve_drop(p.drop);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE = RT * DH * 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int bh = blockIdx.x / p.nsplit, part = blockIdx.x - bh * p.nsplit, b = bh / p.H, h = bh - b * p.H;
-  const int T = p.T, dh = p.dh, ntl = (T + RT - 1) / RT;
+  const int T = p.T, dh = DMA ? DH : p.dh, ntl = (T + RT - 1) / RT;
   const long ld = 3L * p.H * dh, ldc = (long)p.H * dh;
   const short* qb = p.qkv + (long)b * T * ld + h * dh;
   const short* kb_ = qb + p.H * dh;
   const short* vb = kb_ + p.H * dh;
   const short* dob = p.dctx + (long)b * T * ldc + h * dh;
   // only the 16-row blocks that hold queries are staged (like K / V in the other two kernels): T = 577 -> 592 rows,
-  // 2 x 74 KiB + 4.6 KiB of row statistics fit the CU's 160 KiB
-  const int rows_alloc = (T + 15) & ~15;
+  // 2 x 74 KiB + 7.5 KiB of row statistics (each array padded to whole 64-row DMA pieces) fit the CU's 160 KiB
+  const int rows_alloc = (T + 15) & ~15, rows_st = (T + 63) & ~63;
   char* Qimg = smem;
   char* Oimg = smem + rows_alloc * (DH * 2);
   float* lse_s = (float*)(smem + 2 * rows_alloc * (DH * 2));
-  float* del_s = lse_s + rows_alloc;
-  unsigned* rk_s = (unsigned*)(del_s + rows_alloc);  // dropout row keys of the head's query rows
-  load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, rows_alloc, tid, blockDim.x);
-  for (int i = tid; i < rows_alloc; i += blockDim.x) {
-    lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
-    del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
-    rk_s[i] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + i) : 0u;
-  }
-  __syncthreads();
+  float* del_s = lse_s + rows_st;
+  unsigned* rk_s = (unsigned*)(del_s + rows_st);  // dropout row keys of the head's query rows
   const int k00 = (part * p.wpw + wave) * RQ * 16;
   float* csum = p.csum_part ? p.csum_part + ((long)(bh / p.H) * p.nsplit * p.wpw + part * p.wpw + wave) * ld + p.H * dh + h * dh
                             : nullptr;
-  if (k00 >= T) {
-    if (csum && lane < DH / 4 && lane * 4 < dh) {
-      *(f32x4*)(csum + lane * 4) = zero4();
-      *(f32x4*)(csum + p.H * dh + lane * 4) = zero4();
-    }
-    return;
-  }
-
+  const bool idle = k00 >= T;  // DMA form: an idle wave still owes the workgroup its pieces and barriers
   bf16x8 kf[RQ][DH / 32], vf[RQ][DH / 32];
   f32x4 dkt[RQ][DH / 16], dvt[RQ][DH / 16];
+  ImgDma dm = {(int)(blockDim.x >> 6), rows_alloc >> 3, wave, 0};
+  if constexpr (DMA) {
+    // see the dQ kernel: own rows (untracked), then the raw row statistics (64 rows x 4 B per piece), then the Q / dO images in
+    // the order the query loop reads them
+    if (!idle) {
 #pragma unroll
-  for (int rq = 0; rq < RQ; ++rq) {
-    load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, dh, l15, lg);
-    load_own<DH>(vf[rq], vb, ld, k00 + rq * 16, T, dh, l15, lg);
+      for (int rq = 0; rq < RQ; ++rq) {
+        const long row = min(k00 + rq * 16 + l15, T - 1);  // keys past T: nothing of theirs is stored
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) {
+          kf[rq][s] = __builtin_bit_cast(bf16x8, load16_untracked(kb_ + row * ld + s * 32 + lg * 8));
+          vf[rq][s] = __builtin_bit_cast(bf16x8, load16_untracked(vb + row * ld + s * 32 + lg * 8));
+        }
+      }
+    }
+    const unsigned La = lds_addr_of(lse_s), Da = lds_addr_of(del_s);
+    for (int jp = wave; jp < (rows_st >> 6); jp += dm.nwv) {
+      const unsigned off = (unsigned)min(jp * 64 + lane, T - 1) * 4u;
+      lds_dma4_s(p.lse + (long)bh * T, off, La + jp * 256);
+      lds_dma4_s(p.delta + (long)bh * T, off, Da + jp * 256);
+    }
+    const unsigned Qa = lds_addr_of(Qimg), Oa = lds_addr_of(Oimg);
+    for (int jg = wave; jg < dm.npc; jg += dm.nwv) {
+      dma_piece64(Qa, qb, ld, jg, T, lane);
+      dma_piece64(Oa, dob, ldc, jg, T, lane);
+      dm.tot += 2;
+    }
+    wait_vmcnt_dyn(dm.tot);  // everything older than the image pieces: my own rows and my statistics pieces
+    __builtin_amdgcn_sched_barrier(0);
+    if (!idle) {
+#pragma unroll
+      for (int rq = 0; rq < RQ; ++rq)
+#pragma unroll
+        for (int s = 0; s < DH / 32; ++s) asm volatile("" : "+v"(kf[rq][s]), "+v"(vf[rq][s]));  // uses stay behind the wait
+    }
+    __builtin_amdgcn_s_barrier();  // everybody's statistics pieces are in
+    for (int i = tid; i < rows_alloc; i += blockDim.x) {
+      const float lr = lse_s[i], dr = del_s[i];
+      lse_s[i] = i < T ? lr * LOG2E : INFINITY;
+      del_s[i] = i < T ? dr : 0.f;
+      rk_s[i] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + i) : 0u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // published by the first tile's barrier below
+  } else {
+    load_all_tiles2<DH>(Qimg, qb, ld, Oimg, dob, ldc, T, dh, rows_alloc, tid, blockDim.x);
+    for (int i = tid; i < rows_alloc; i += blockDim.x) {
+      lse_s[i] = i < T ? p.lse[(long)bh * T + i] * LOG2E : INFINITY;
+      del_s[i] = i < T ? p.delta[(long)bh * T + i] : 0.f;
+      rk_s[i] = p.drop.thr ? drop_rowkey(p.drop, (unsigned long long)bh * T + i) : 0u;
+    }
+    __syncthreads();
+    if (idle) {
+      if (csum && lane < DH / 4 && lane * 4 < dh) {
+        *(f32x4*)(csum + lane * 4) = zero4();
+        *(f32x4*)(csum + p.H * dh + lane * 4) = zero4();
+      }
+      return;
+    }
+#pragma unroll
+    for (int rq = 0; rq < RQ; ++rq) {
+      load_own<DH>(kf[rq], kb_, ld, k00 + rq * 16, T, dh, l15, lg);
+      load_own<DH>(vf[rq], vb, ld, k00 + rq * 16, T, dh, l15, lg);
+    }
+  }
+#pragma unroll
+  for (int rq = 0; rq < RQ; ++rq)
 #pragma unroll
     for (int i = 0; i < DH / 16; ++i) dkt[rq][i] = dvt[rq][i] = zero4();
-  }
   const float c = p.scale * LOG2E;
   const float dscale = p.drop.thr ? p.drop.scale : 1.0f;
 
   for (int qt = 0; qt < ntl; ++qt) {
     const int qb0 = qt * RT;
+    if constexpr (DMA) {  // three rendezvous, as in the dQ kernel: tile 0; tiles 1-2; the rest
+      if (qt == 0 || qt == 1) {
+        wait_vmcnt_dyn(dm.allowed(qt ? 2 : 0, 2));
+        __builtin_amdgcn_s_barrier();
+      } else if (qt == 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (idle) continue;
+    }
     const char* Qt = Qimg + qt * TILE;
     const char* Ot = Oimg + qt * TILE;
 #pragma unroll
@@ -1163,6 +1364,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
       }
     }
   }
+  if (DMA && idle) {
+    if (csum && lane < DH / 4) {
+      *(f32x4*)(csum + lane * 4) = zero4();
+      *(f32x4*)(csum + p.H * dh + lane * 4) = zero4();
+    }
+    return;
+  }
   f32x4 csk[DH / 16], csv[DH / 16];
 #pragma unroll
   for (int dt = 0; dt < DH / 16; ++dt) csk[dt] = csv[dt] = zero4();
@@ -1197,38 +1405,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(AttnArgs p) {
         *(f32x4*)(csum + p.H * dh + d) = tv;
       }
     }
-  }
-}
-
-// ======================================================================================= fused backward (T <= 240)
-// ONE kernel per attention backward when a head's Q, dO and K fit the LDS together with one half of the dS matrix: one
-// workgroup of 8 waves per (batch, head); every tensor of the head is read from HBM exactly once and S / P / dP are
-// recomputed once (5 products instead of the two-kernel path's 7: the resident dQ + dK/dV pair above moved 1.36 GB per
-// ViT-B layer and ran at HBM speed).  No atomics (the reference trains with deterministic=True, basemodule.py:250):
-//   phase A (owner = key, as in the dK/dV kernel): wave w keeps K, V of keys [32w, 32w+32) in registers and walks the
-//     query pairs (32 rows) of the current half: S = Q K^T, dP = dO V^T, P, dS; dV += P~^T dO, dK += dS^T Q stay in
-//     registers; dS (bf16) goes to the LDS as [key][query] -- 4 consecutive queries of one key per lane, one 8-byte store;
-//   phase B (owner = query): wave w takes query tile w of the half and sums dQ = dS K over ALL keys, both operands by
-//     transposing reads (K image [key][d], dS image [key][query]); dQ leaves in bf16, its column sums join the others.
-// Two halves of 128 queries keep the dS image at 60 KiB: LDS = 3 x 26 KiB (Q, dO, K) + 58.5 KiB + statistics = 138 KiB at
-// T = 197, one workgroup per CU.  delta = rowsum(dO o (O + O_lo)) is computed up front from global O (loads issued before
-// the staging barrier) and dO from the LDS.
-// Dropout multipliers of 4 consecutive query rows at ONE key for the key-owner orientation of the backward kernels, from
-// the rows' keys `rk` (staged in the LDS once per head).  The mask word belongs to a (row, key pair): lanes l15 and l15 ^ 1
-// hold the two keys of a pair and would evaluate the same four words; instead the even lane evaluates rows 0, 1, the odd
-// lane rows 2, 3, and they trade results across the lane pair by DPP: 2 words + 2 moves per 4 elements instead of 4 words.
-__device__ __forceinline__ void drop_mask4_keyowner(const DropCfg& d, const u32x4& rk, unsigned key, int l15, float (&mk)[4]) {
-  const unsigned odd = (unsigned)l15 & 1u;
-  const unsigned ha = drop_bits(odd ? rk[2] : rk[0], key >> 1);
-  const unsigned hb = drop_bits(odd ? rk[3] : rk[1], key >> 1);
-  // lane ^ 1 by DPP quad_perm [1,0,3,2] (one VALU move; __shfl_xor would go through ds_bpermute)
-  const unsigned oa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xF, 0xF, false);
-  const unsigned ob = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xF, 0xF, false);
-  const unsigned h[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const unsigned r16 = odd ? (h[r] >> 16) : (h[r] & 0xFFFFu);  // key parity == lane parity (key tiles start at even keys)
-    mk[r] = r16 >= d.thr ? d.scale : 0.f;
   }
 }
 
@@ -1741,9 +1917,9 @@ constexpr int RES_MAX_T = 592, RES_MAX_DH = 64, RES_RQ = 2;
 int g_attn_res_max_t = RES_MAX_T;  // vit_set_option("attn_res_max_t"): larger T goes to the tiled kernels
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
 
-static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + two f32 rows of statistics
-  const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15;
-  return 2 * rows * dhp * 2 + 3 * rows * 4 <= 160 * 1024;
+static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + three f32 rows of statistics
+  const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15, rows_st = (T + 63) & ~63;
+  return 2 * rows * dhp * 2 + 3 * rows_st * 4 <= 160 * 1024;
 }
 
 // max_waves: 8 for the backward kernels (their csum partial rows share one geometry; dK/dV needs 216 VGPRs = 2 waves per
@@ -1780,6 +1956,15 @@ static int launch_res(const AttnArgs& a, size_t smem, hipStream_t st, int max_wa
   do {                                                                                      \
     if (a.dh <= 32) { constexpr int DH_ = 32; rc = launch_res<KERNEL<32, RES_RQ>>(a, smem_expr, st); }        \
     else { constexpr int DH_ = 64; rc = launch_res<KERNEL<64, RES_RQ>>(a, smem_expr, st); }                    \
+  } while (0)
+// the two resident backward kernels: head_dim exactly 64 takes the DMA prologue (images requested in reading order, per-tile
+// counted waits); g_attn_bwd_dma = 0 (vit_set_option("attn_bwd_dma")) keeps the register-staged form for A/B runs
+int g_attn_bwd_dma = 1;
+#define DISPATCH_RES_BWD(KERNEL, a, smem_expr, st, rc)                                      \
+  do {                                                                                      \
+    if (a.dh == 64 && g_attn_bwd_dma) { constexpr int DH_ = 64; rc = launch_res<KERNEL<64, RES_RQ, true>>(a, smem_expr, st); } \
+    else if (a.dh <= 32) { constexpr int DH_ = 32; rc = launch_res<KERNEL<32, RES_RQ, false>>(a, smem_expr, st); } \
+    else { constexpr int DH_ = 64; rc = launch_res<KERNEL<64, RES_RQ, false>>(a, smem_expr, st); }             \
   } while (0)
 
 // ======================================================================================= fp32 attention (precision '32')
@@ -2405,9 +2590,9 @@ static int attention_bwd_impl(vit_handle h, const void* qkv, const void* ctx, co
     return VIT_OK;
   }
   if (T <= g_attn_res_max_t && T <= RES_MAX_T && dh <= RES_MAX_DH && res_fits(T, dh)) {
-    DISPATCH_RES(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
+    DISPATCH_RES_BWD(attn_bwd_dq_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2), st, rc);
     if (rc != VIT_OK) return rc;
-    DISPATCH_RES(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 3 * (size_t)((T + 15) & ~15) * 4), st, rc);
+    DISPATCH_RES_BWD(attn_bwd_dkv_res_kernel, a, (2 * (size_t)((T + 15) & ~15) * DH_ * 2 + 3 * (size_t)((T + 63) & ~63) * 4), st, rc);
     return rc;
   }
   dim3 grid(cdiv(cdiv(T, 16), AW), B * H);

@@ -174,6 +174,10 @@ class Trainer:
         # 'fp32' (the reference's DDP) | 'bf16' (half the bytes on the links, the sum rounded in bf16: an option, see ddp.py)
         self.grad_dtype = str(config.get("ddp_grad_dtype", os.environ.get("VIT_DDP_GRAD_DTYPE", "fp32")))
         self.max_bucket_elems = int(config.get("ddp_max_bucket_elems", os.environ.get("VIT_DDP_MAX_BUCKET_ELEMS", 64 << 20)))
+        # train.ddp_reserve_cus: CUs the persistent one-workgroup-per-CU kernels leave to the collective (an int), or 'auto':
+        # fit() times a few steps on its first batch at 0 / 8 / 16 / 32 and keeps the fastest (autotune_reserve_cus)
+        self.reserve_cus_cfg = config.get("ddp_reserve_cus", os.environ.get("VIT_DDP_RESERVE_CUS", 0))
+        self.reserve_cus = 0
         # train.hip_graph: replay the optimisation step as one captured hipGraph (vit_amd/graph.py; single GPU only)
         self.use_graph = bool(config.get("hip_graph", False))
         self._graphed = None
@@ -254,6 +258,40 @@ class Trainer:
         if self.save_enabled and not self.fast_dev_run:
             self.checkpointer = Checkpointer(os.environ.get("CKPT_DIR", "./checkpoints"), self.monitor, self.monitor_mode)
         self._ready_for = module
+
+    # ------------------------------------------------------------------ room for the collective
+    def autotune_reserve_cus(self, module, batch, candidates=(0, 8, 16, 32), steps=3):
+        """Data-parallel runs only: pick how many CUs the one-workgroup-per-CU kernels (ping-pong GEMMs, pair-pipelined attention
+        backward) leave free for the collective's kernels that overlap the backward (`vit_set_option("reserve_cus")`), by timing
+        `steps` optimisation steps on `batch` at each candidate (median of per-step hipEvent times, MAX over ranks) and keeping
+        the fastest; every rank takes the same decision.  The steps are real optimisation steps: call it during warm-up
+        (bench.py does; `fit` only with `train.ddp_reserve_cus: auto`, on its first batch).  Returns {candidate: ms}.
+        Reference: Lightning's 'ddp' strategy overlaps NCCL with backward on a GPU whose kernels do not own whole SMs; a
+        persistent grid that owns every CU must make that room itself."""
+        from . import _cabi
+
+        if not self.exchanging:
+            return {}
+        dist = torch.distributed
+        out = {}
+        for c in candidates:
+            _cabi.set_option("reserve_cus", int(c))
+            self.training_step(module, batch, 0)  # the grids' first launch at this size
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            torch.cuda.synchronize()
+            dist.barrier()
+            ev[0].record()
+            for i in range(steps):
+                self.training_step(module, batch, i)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            t = torch.tensor([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[int(c)] = float(t.median())
+        best = min(out, key=lambda k: (out[k], k))
+        _cabi.set_option("reserve_cus", best)
+        self.reserve_cus = best
+        return out
 
     # ------------------------------------------------------------------ one optimisation step
     def training_step(self, module, batch, batch_idx):
@@ -404,6 +442,19 @@ class Trainer:
         self._es_best, self._es_bad = None, 0
         self._setup(module)
         first_epoch = self._resume(module, ckpt_path) if ckpt_path else 0
+        if self.exchanging and str(self.reserve_cus_cfg) not in ("0", "", "None"):
+            if str(self.reserve_cus_cfg).lower() == "auto":
+                module.train()
+                first = next(iter(train_loader), None)
+                if first is not None:
+                    tuned = self.autotune_reserve_cus(module, _to_device(first, self.device))
+                    if self.verbose:
+                        print(f"[trainer] reserve_cus autotune (ms per step) {tuned} -> {self.reserve_cus}")
+            else:
+                from . import _cabi
+
+                self.reserve_cus = int(self.reserve_cus_cfg)
+                _cabi.set_option("reserve_cus", self.reserve_cus)
         self.freeze_heap()
         epochs = 1 if self.fast_dev_run else self.max_epochs
         for epoch in range(first_epoch, epochs):
