@@ -736,3 +736,45 @@ def test_full_size_vit_l_training_step(dev):
     moved = [k for k, v in module.model.state_dict().items() if not torch.equal(v, w0[k])]
     frozen = [k for k in w0 if k not in moved]
     assert all("pooler" in k for k in frozen), frozen
+
+
+def test_bench_contract_single_gpu(dev):
+    """The driver's contract on the line `bench.py` prints (one JSON object on stdout): metric / value / unit / n_gpus / steps /
+    warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, `roofline` with
+    bound / achieved / peak / unit / frac / traffic, `cpu_baseline` with value / unit / cores / kind / sample, and the round-4
+    `timing` object: `value` comes from the MEDIAN per-step hipEvent time, the region mean is reported beside it, the start-up
+    heap is frozen and no garbage collection ran inside the timed region.  (Tiny workload: a contract test, not a measurement.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VIT_DIST_SINGLE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--workload", "vit_tiny16_32",
+                        "--batch", "256"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    doc = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "timing", "mean_ms_per_step"):
+        assert k in doc, k
+    assert doc["n_gpus"] == 1 and doc["steps"] == 6 and doc["warmup"] == 2 and doc["higher_is_better"] is True
+    assert doc["scaling"] == "weak" and doc["vs_baseline"] is None and doc["dtype"] == "bf16" and doc["data"] == "synthetic"
+    assert "workload" in doc["config"] and "model" not in doc["config"]
+    rf = doc["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = doc["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    tm = doc["timing"]
+    assert len(tm["step_ms"]) == 6 and tm["heap_frozen"] is True and tm["gc_in_region"] == []
+    srt = sorted(tm["step_ms"])
+    assert abs(doc["ms_per_step"] - 0.5 * (srt[2] + srt[3])) < 2e-3
+    assert abs(doc["value"] - 256 / (doc["ms_per_step"] * 1e-3)) <= 1e-3 * doc["value"]
+    assert abs(doc["mean_ms_per_step"] * 6 - tm["region_wall_ms"]) < 1e-2 * tm["region_wall_ms"]
