@@ -134,6 +134,13 @@ typedef struct vit_gemm_desc {
   int accumulate;          /* split_k path: C += result instead of C = result */
   float* colsum_out;       /* optional f32 [N]: column sums of C as stored (a Linear's bias gradient when C is the gradient
                             * of its output); summed inside the epilogue where the kernel can, else by a vit_colsum pass */
+  /* Rotary position embedding of the fused QKV projection's output (src/models/vit_with_rope.py:58-60, rope.py:116-131):
+   * columns [0, rope_cols) of C are heads of rope_dh columns whose element i pairs with element i + rope_dh / 2, row m is token
+   * m % rope_T; cos / sin: f32 [rope_T, rope_dh / 2] (vit_rope_qk's tables).  NULL = off.  The ping-pong core rotates in its
+   * epilogue, on the f32 values before the one rounding to bf16 (rope_dh 16 / 32 / 64, rope_cols a multiple of 64); every
+   * other case runs vit_rope_qk on C right after the product -- same contract either way. */
+  const float* rope_cos; const float* rope_sin;
+  int rope_T, rope_dh, rope_cols;
 } vit_gemm_desc;
 int vit_gemm(vit_handle h, const vit_gemm_desc* d, vit_stream stream);
 /* Symbol (as rocprofv3 prints it, without the "void vit::" prefix and argument list) of the kernel the calling thread's

@@ -804,3 +804,47 @@ def test_attention_bwd_fused_matches_two_kernel_path(dev, B, H, T, dh, drop):
         dd = b_[0].double().view(B * T, 3, H * dh)
         for i in range(3):
             assert rel(dd[:, i], g[:, i]) < 1.2e-2, (i, rel(dd[:, i], g[:, i]))
+
+
+@pytest.mark.parametrize("H,dh", [(4, 64), (8, 32), (16, 16), (2, 128)])
+@pytest.mark.parametrize("M,T", [(512, 197), (1024, 128)])
+def test_gemm_rope_epilogue(dev, H, dh, M, T):
+    """r04 ('RoPE on Q / K fused into K3's epilogue'; src/models/vit_with_rope.py:58-60, rope.py:116-131): vit_gemm
+    with the rope fields rotates the q / k columns of a fused QKV projection.  On the ping-pong core (tile-aligned problem, head_dim
+    16 / 32 / 64) that happens INSIDE the epilogue, on the f32 sums before the one rounding to bf16 -- the kernel symbol says so --
+    and for every other case (head_dim 128 here; unaligned shapes; f32 operands) the library runs vit_rope_qk behind the product.
+    Both against an fp64 projection + rotate_half rotation; the fused form must be at least as close as product-then-pass."""
+    import vit_amd.functional as vf
+    from vit_amd import _cabi
+
+    D = H * dh
+    K = 256
+    x = bf(randn((M, K), dev, 300, 0.5))
+    W = bf(randn((3 * D, K), dev, 301, 0.1))
+    bias = randn((3 * D,), dev, 302)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, dh, 2).float() / dh))
+    fr = torch.outer(torch.arange(T).float(), inv)
+    cos, sin = fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev)
+    out = vf.gemm(x, W, M=M, N=3 * D, K=K, bias=bias, rope=(cos, sin, T, dh, 2 * D))
+    sym = _cabi.load().vit_last_gemm_kernel().decode()
+    assert ("<0, 0, 8, 8>" in sym) == (dh <= 64), sym  # the rotating epilogue wherever a wave's 64 columns are whole heads
+    # fp64 reference
+    y = x.double() @ W.double().t() + bias.double()
+    t = (torch.arange(M, device=dev) % T)
+    c, s = cos.double()[t], sin.double()[t]                      # [M, dh/2]
+    ref = y.clone()
+    for part in range(2):
+        blk = y[:, part * D:(part + 1) * D].view(M, H, dh)
+        x1, x2 = blk[..., : dh // 2], blk[..., dh // 2:]
+        rot = torch.cat([x1 * c[:, None] - x2 * s[:, None], x2 * c[:, None] + x1 * s[:, None]], -1)
+        ref[:, part * D:(part + 1) * D] = rot.reshape(M, D)
+    e_fused = rel(out, ref)
+    assert e_fused < 4e-3, e_fused
+    assert rel(out[:, 2 * D:], y[:, 2 * D:]) < 4e-3  # the v third is the plain projection
+    # product, then the separate pass (what every round before did): rounds twice
+    two = vf.gemm(x, W, M=M, N=3 * D, K=K, bias=bias)
+    vf.rope_qk(two, cos, sin, T, H, dh)
+    e_two = rel(two, ref)
+    assert e_fused <= e_two * 1.02 + 1e-6, (e_fused, e_two)
+    if dh > 64:
+        assert torch.equal(out, two)  # the library's own fall-back IS that pass

@@ -389,6 +389,61 @@ def test_rope_model_matches_oracle(dev, precision):
     assert checked > 20
 
 
+def test_rope_model_with_the_rotating_epilogue(dev):
+    """pos_encoding_type='rope' at a tile-aligned geometry (hidden 256, 4 heads of 64, T = 129, rows padded to 256): in
+    bf16-mixed the fused QKV projection of every layer runs the ping-pong core's ROTATING epilogue (r04: the rotation is no longer
+    a separate pass there; the backward still rotates dq / dk back in its own pass).  Against the CPU oracle run here on the same
+    weights and inputs: logits, first-layer attention map, loss and every gradient, at the bf16 gates of the other model tests;
+    and the library did launch the rotating epilogue."""
+    from oracle import refvit
+    from vit_amd import _cabi
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    kw = dict(image_size=4096, patch_size=32, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, stride_size=32,
+              pos_encoding_type="rope", rope_base=10000.0)
+    rc = refvit.RefConfig(loss_name="mae", **kw)
+    sd = refvit.make_state_dict(rc, 5)
+    x, _, labels = refvit.make_inputs(rc, 6, 9)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = refvit.forward(rc, params, x, labels, output_attentions=True)
+    ref.loss.backward()
+    grads = {k: p.grad.detach() for k, p in params.items() if p.grad is not None}
+    model = MyViT(ViTConfig(task_type="reg", **kw), loss_name="mae")
+    model.set_precision("bf16-mixed")
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    seen = []
+    import vit_amd.functional as vf
+    orig = vf.gemm
+
+    def spy(a, b, **k):
+        out = orig(a, b, **k)
+        if k.get("rope") is not None:
+            seen.append(_cabi.load().vit_last_gemm_kernel().decode())
+        return out
+
+    vf.gemm = spy
+    try:
+        out = model(x.to(dev), labels=labels.to(dev), output_attentions=True)
+    finally:
+        vf.gemm = orig
+    assert len(seen) == 2 and all("<0, 0, 8, 8>" in s_ for s_ in seen), seen
+    assert rel(out.logits, ref.logits.detach()) < 1.5e-2
+    assert rel(out.attentions[0], ref.attentions[0].detach()) < 1.5e-2
+    assert abs(float(out.loss) - float(ref.loss)) <= 2 * float(ref.loss) ** 0.5 * 1.5e-2 + 1e-6
+    model(x.to(dev), labels=labels.to(dev)).loss.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if name not in grads or p.grad is None or float(grads[name].norm()) < 1e-6:
+            continue
+        mine, g_ = p.grad.reshape(grads[name].shape).cpu(), grads[name]
+        cos = float(torch.dot(mine.flatten().double(), g_.flatten().double()) / (mine.double().norm() * g_.double().norm()))
+        assert cos > 0.999 and rel(mine, g_) < 8e-2, (name, cos, rel(mine, g_))
+        checked += 1
+    assert checked > 20
+
+
 @pytest.mark.parametrize("precision", ["32", "bf16-mixed"])
 def test_padded_rows_do_not_leak(dev, precision):
     """hidden % 256 == 0 with B*T NOT a multiple of 256: the engine pads the GEMM row count to the 256-row tiles of the

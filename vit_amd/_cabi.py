@@ -42,6 +42,8 @@ class GemmDesc(C.Structure):
         ("split_k", C.c_int),
         ("accumulate", C.c_int),
         ("colsum_out", C.c_void_p),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("rope_T", C.c_int), ("rope_dh", C.c_int), ("rope_cols", C.c_int),
     ]
 
 

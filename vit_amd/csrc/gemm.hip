@@ -478,11 +478,23 @@ int launch_splitk_reduce(const float* slab, float* C, long ldc, int M, int N, in
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 thread_local int g_colsum_fused = 0;  // set by a core whose epilogue produced d->colsum_out itself
+thread_local int g_rope_fused = 0;    // set by a core whose epilogue applied d->rope_* itself
 static int gemm_launch_core(vit_handle h, const vit_gemm_desc* d, hipStream_t st);
 
 int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   g_colsum_fused = 0;
-  const int rc = gemm_launch_core(h, d, st);
+  g_rope_fused = 0;
+  if (d && d->rope_cos) {
+    VIT_CHECK(d->rope_sin && d->rope_T > 0 && d->rope_dh >= 8 && (d->rope_dh % 8) == 0 && d->rope_cols > 0 &&
+                  (d->rope_cols % (2 * d->rope_dh)) == 0 && d->rope_cols <= d->N && d->rows_per_batch == 0 && !d->colsum_out &&
+                  d->act == VIT_ACT_NONE && !d->residual && d->split_k <= 1,
+              VIT_ERR_ARG, "vit_gemm: rope needs sin, T > 0, head_dim %% 8 == 0, rope_cols = 2 x heads x head_dim <= N, and a plain "
+                           "(bias / dropout-free) projection without row map, column sums, residual or split-K");
+  }
+  int rc = gemm_launch_core(h, d, st);
+  if (rc == VIT_OK && d->rope_cos && !g_rope_fused)  // the core had no rotating epilogue for this shape: the separate pass
+    rc = vit_rope_qk(h, d->C, d->c_dtype, d->rope_cos, d->rope_sin, d->M, d->rope_T, d->rope_cols / (2 * d->rope_dh), d->rope_dh,
+                     d->ldc, 0, (vit_stream)st);
   if (rc != VIT_OK || !d->colsum_out || g_colsum_fused) return rc;
   VIT_CHECK(d->rows_per_batch == 0, VIT_ERR_ARG, "vit_gemm: colsum_out with a row map is not supported");
   return vit_colsum(h, d->C, d->c_dtype, d->ldc, d->colsum_out, d->M, d->N, 0, (vit_stream)st);

@@ -55,6 +55,8 @@ struct Gemm2Args {
   int tail_first, tail_n;  // half-tile kernel: tiles [tail_first, tail_first + tail_n), two workgroups each
   int slab_tiles;  // split-K over the tail tiles: the slab is compact, [split][tile - tail_first][256][256] f32 (0: [split][M][N])
   int grp2;  // ping-pong kernel: XCDs 0-3 walk the lower half of the N-tiles, XCDs 4-7 the upper half (see tile_coords)
+  const float* rope_cos; const float* rope_sin;  // epilogue 8: rotary embedding of columns [0, rope_cols) (vit_gemm_desc)
+  int rope_T, rope_dh, rope_cols;
 #ifdef VIT_PP_STAMP
   unsigned long long* stamps;  // diagnostic build: [8 waves][8] summed s_memtime deltas of workgroup `stamp_block`
   int stamp_block;
@@ -159,6 +161,10 @@ void* ctx_workspace(vit_handle h, size_t* bytes);
 //   5 = * gelu'(aux_in) -> bf16         dX of FC2; the wave's aux rows are fetched in two batches of 8 loads, up front
 //   6 = plain -> bf16                   dX = dY W
 //   7 = plain -> f32 (C or split-K slab)  dW = dY^T X
+//   8 = +bias, rotary embedding of the q / k columns -> bf16      the fused QKV projection under pos_encoding_type 'rope'
+//       (src/models/vit_with_rope.py:58-60): a wave's 64 output columns are whole heads (head_dim 16 / 32 / 64), so the
+//       rotation partner i + head_dim / 2 of a lane's 8 columns sits 1 / 2 / 4 lanes away in the row-major layout behind the
+//       LDS transpose: one ds_swizzle per value, the f32 values rotated BEFORE the one rounding to bf16
 // Same per-wave LDS transpose as tile_epilogue on the way in; on the way out a lane owns 16 bytes of output.
 template <int FAST, int NI>
 __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
@@ -211,7 +217,7 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
 #endif
   const unsigned half_cols = (unsigned)(p.N >> 1);
   f32x4 bv0 = (f32x4){0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
-  if ((FAST == 3 || FAST == 4) && p.bias) {
+  if ((FAST == 3 || FAST == 4 || FAST == 8) && p.bias) {
     bv0 = *(const f32x4*)(p.bias + n);
     bv1 = *(const f32x4*)(p.bias + n + 4);
   }
@@ -319,6 +325,29 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
           }
         }
       }
+      if (FAST == 8 && n0 < p.rope_cols) {  // wave-uniform: this wave's 64 columns are q or k heads
+        const int hl = p.rope_dh >> 4;      // lanes per half head: 1, 2 or 4
+        const int t = (int)m % p.rope_T;
+        const long to = (long)t * (p.rope_dh >> 1) + (cg & (hl - 1)) * 8;
+        const f32x4 c0 = *(const f32x4*)(p.rope_cos + to), c1 = *(const f32x4*)(p.rope_cos + to + 4);
+        const f32x4 s0 = *(const f32x4*)(p.rope_sin + to), s1 = *(const f32x4*)(p.rope_sin + to + 4);
+        const float sg = (cg & hl) ? 1.f : -1.f;  // first half: x1 cos - x2 sin; second half: x2 cos + x1 sin
+        float px[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int v = __builtin_bit_cast(int, o[r]);
+          int w;  // the partner lane's value: lane ^ hl inside the 8-lane row segment (ds_swizzle bit mode: and 0x1F, xor hl)
+          if (hl == 4) w = __builtin_amdgcn_ds_swizzle(v, 0x101F);
+          else if (hl == 2) w = __builtin_amdgcn_ds_swizzle(v, 0x081F);
+          else w = __builtin_amdgcn_ds_swizzle(v, 0x041F);
+          px[r] = __builtin_bit_cast(float, w);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = fmaf(o[r], c0[r], sg * px[r] * s0[r]);
+          o[4 + r] = fmaf(o[4 + r], c1[r], sg * px[4 + r] * s1[r]);
+        }
+      }
       if (FAST == 3 && p.drop.thr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -400,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(Gemm2Args p) {
   constexpr int XA0 = 0, XB0 = 1, XB1 = 2, XA1 = 3;
   // vmcnt budget of the four phases after an epilogue: the usual 8 + the FEWEST vector-memory operations that epilogue
   // issues per wave (its stores: 16 x 16 B for the bf16 kinds, 32 otherwise) -- a lower bound keeps the wait conservative
-  constexpr int RELAX = INFL + ((EPI >= 3 && EPI <= 6) ? 16 : 32);
+  constexpr int RELAX = INFL + (((EPI >= 3 && EPI <= 6) || EPI == 8) ? 16 : 32);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1092,6 +1121,7 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
   if (epi == 4) return launch_stag<0, 0, 4>(a, grid, st);
   if (epi == 5) return launch_stag<0, 1, 5>(a, grid, st);
   if (epi == 6) return launch_stag<0, 1, 6>(a, grid, st);
+  if (epi == 8) return launch_stag<0, 0, 8>(a, grid, st);
   if (epi == 7) {
     if (at && bt) return launch_stag<1, 1, 7>(a, grid, st);
     if (!at && !bt) return launch_stag<0, 0, 7>(a, grid, st);  // the next two: K-slices of a forward / dX GEMM's tail tiles
@@ -1104,7 +1134,7 @@ static int launch_stag_cfg(const Gemm2Args& a, int at, int bt, int epi, dim3 gri
   return launch_stag<1, 1, 0>(a, grid, st);
 }
 
-extern thread_local int g_colsum_fused;  // gemm.hip
+extern thread_local int g_colsum_fused, g_rope_fused;  // gemm.hip
 #ifdef VIT_PP_STAMP
 unsigned long long* g_pp_stamps = nullptr;
 int g_pp_stamp_block = 0;
@@ -1178,6 +1208,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     a.residual = (const float*)d->C; a.ldres = d->ldc;
   }
   a.alpha = d->alpha;
+  a.rope_cos = d->rope_cos; a.rope_sin = d->rope_sin; a.rope_T = d->rope_T; a.rope_dh = d->rope_dh; a.rope_cols = d->rope_cols;
   a.act = d->act; a.c_dtype = d->c_dtype;
   a.drop = make_drop_h(h, d->dropout_p, d->seed, d->site);
   a.rpb = d->rows_per_batch; a.orb = d->out_batch_rows; a.roff = d->out_row_offset;
@@ -1205,9 +1236,14 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_BF16 && !d->a_trans && d->b_trans &&
              splits == 1) epi5 = 6;
     else if (epi == 0 && plain && !a.bias && !a.drop.thr && d->c_dtype == VIT_F32 && d->a_trans && d->b_trans) epi5 = 7;
+    // rotary embedding requested: the rotating epilogue where a wave's 64 columns are whole heads, else the caller (gemm_launch)
+    // runs the separate pass behind this launch
+    if (d->rope_cos) {
+      if (epi5 == 3 && !a.drop.thr && (d->rope_dh == 16 || d->rope_dh == 32 || d->rope_dh == 64) && (d->rope_cols % 64) == 0) epi5 = 8;
+    }
     // the bf16 fast epilogues store through 32-bit buffer offsets (raw buffer stores, sc1): outputs past 2 GiB keep the
     // generic epilogue (a clamped descriptor would drop the stores beyond it silently)
-    if (epi5 >= 3 && epi5 <= 6 &&
+    if (((epi5 >= 3 && epi5 <= 6) || epi5 == 8) &&
         ((unsigned long long)d->M * d->ldc * 2 >= 0x7FFFFFF0ull || (d->aux_out && (unsigned long long)d->M * d->ldaux * 2 >= 0x7FFFFFF0ull)))
       epi5 = epi;
   }
@@ -1262,6 +1298,7 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     const int at = epi ? 0 : d->a_trans, bt = epi == 1 ? 0 : (epi == 2 ? 1 : d->b_trans);
     snprintf(g_last_gemm, sizeof(g_last_gemm), "gemm3_kernel<%d, %d, %d, %d>", at, bt, epi5, 8);
   }
+  if (epi5 == 8) g_rope_fused = 1;
   int r = launch_stag_cfg(a, d->a_trans, d->b_trans, epi5, grid, st);
   if (r == VIT_OK && half_tail && st_splits > 1) {
     Gemm2Args b = a;

@@ -377,9 +377,10 @@ class ViTEngine:
                 self._ln(xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
             else:
                 self._ln_res(a["x1"][jprev], y, xin, pre + "layernorm_before", a["h1"][j], a["mean1"][j], a["rstd1"][j])
-            vf.gemm(a["h1"][j], self._qkv16(i), M=Mp, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat))
-            if rope is not None:  # vit_with_rope.py:58-60: q, k rotated per head before the scores
-                vf.rope_qk(a["qkv"][j], rope[0], rope[1], T, H, dh)
+            # vit_with_rope.py:58-60: q, k rotated per head before the scores -- inside the projection's epilogue where the
+            # kernel has one (f32 values, one rounding), by a vit_rope_qk pass behind it otherwise (the library decides)
+            vf.gemm(a["h1"][j], self._qkv16(i), M=Mp, N=3 * D, K=D, out=a["qkv"][j], bias=self._qkv_bias(i, self.flat),
+                    rope=None if rope is None else (rope[0], rope[1], T, dh, 2 * D))
             vf.attention_fwd(a["qkv"][j], B, H, T, dh, scale, dropout=(pa, seed, self._site(i, 0)), ctx=a["ctx"][j],
                              lse=a["lse"][j], ctx_lo=a["ctx_lo"][j])
             if output_attentions:

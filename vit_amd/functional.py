@@ -66,7 +66,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
          act: int = ACT_NONE, aux_out: Optional[torch.Tensor] = None, aux_in: Optional[torch.Tensor] = None,
          dropout: Dropout = NO_DROP, residual: Optional[torch.Tensor] = None, row_map: Tuple[int, int, int] = (0, 0, 0),
          out_rows: Optional[int] = None, split_k: int = 0, accumulate: bool = False,
-         colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         colsum_out: Optional[torch.Tensor] = None,
+         rope: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int]] = None) -> torch.Tensor:
+    """`rope = (cos, sin, T, head_dim, cols)`: rotary embedding of columns [0, cols) of the output (the q / k thirds of a fused QKV
+    projection; cos / sin: f32 [T, head_dim / 2]) -- in the GEMM's epilogue where the kernel can, by a vit_rope_qk pass behind it
+    otherwise (the library decides; same result contract)."""
     h = _h(a)
     if a.dtype != b.dtype or a.dtype not in _DT:
         raise _cabi.VitError(f"gemm: operands must both be bf16 or both f32 (got {a.dtype}, {b.dtype})")
@@ -94,6 +98,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
             raise _cabi.VitError(f"gemm: colsum_out must have N={N} elements")
         d.colsum_out = colsum_out.data_ptr()
         h.ensure_workspace(max(2 * (-(-M // 256)), 2048) * N * 4)
+    if rope is not None:
+        cos, sin, rT, rdh, rcols = rope
+        _chk(cos, torch.float32, "gemm rope cos")
+        _chk(sin, torch.float32, "gemm rope sin")
+        if cos.numel() != rT * (rdh // 2) or sin.numel() != cos.numel():
+            raise _cabi.VitError(f"gemm: rope tables must be [T={rT}, head_dim/2={rdh // 2}]")
+        d.rope_cos, d.rope_sin, d.rope_T, d.rope_dh, d.rope_cols = cos.data_ptr(), sin.data_ptr(), int(rT), int(rdh), int(rcols)
     if split_k != 0 and split_k != 1:
         if split_k < 0:  # upper bound over the automatic choices of both GEMM cores (gemm.hip / gemm2.hip)
             tiles = -(-M // 128) * -(-N // 128)
