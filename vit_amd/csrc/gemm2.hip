@@ -164,7 +164,7 @@ void* ctx_workspace(vit_handle h, size_t* bytes);
 //   8 = +bias, rotary embedding of the q / k columns -> bf16      the fused QKV projection under pos_encoding_type 'rope'
 //       (src/models/vit_with_rope.py:58-60): a wave's 64 output columns are whole heads (head_dim 16 / 32 / 64), so the
 //       rotation partner i + head_dim / 2 of a lane's 8 columns sits 1 / 2 / 4 lanes away in the row-major layout behind the
-//       LDS transpose: one ds_swizzle per value, the f32 values rotated BEFORE the one rounding to bf16
+//       LDS transpose: one ds_bpermute per value, the f32 values rotated BEFORE the one rounding to bf16
 // Same per-wave LDS transpose as tile_epilogue on the way in; on the way out a lane owns 16 bytes of output.
 template <int FAST, int NI>
 __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, const Gemm2Args& p, int m0, int n0, int split,
@@ -224,6 +224,21 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // column sums of the stored (bf16-rounded) values
   const bool want_cs = p.colsum_part != nullptr;
   u32x4 au[4][2];  // FAST == 5: the aux rows of four 16-row blocks at a time (two batches per tile; one batch spills)
+  // FAST == 8: cos / sin of this lane's 8 frequencies at its current token (rc*, rs*), advanced by a rotation of 8 tokens per row
+  // chunk (k8*: table row 8) instead of 64 table loads per tile, each of which would be waited for in the open (first form,
+  // r04: QKV 167 -> 217 us, exactly what the separate pass had cost)
+  f32x4 rc0, rc1, rs0, rs1, k8c0, k8c1, k8s0, k8s1;
+  int rt = 0;
+  const int rope_peer = (lane ^ (p.rope_dh >> 4)) << 2;  // ds_bpermute byte address of the lane that holds column i +- dh / 2
+  if (FAST == 8 && n0 < p.rope_cols) {
+    const int hl_ = p.rope_dh >> 4, hd = p.rope_dh >> 1, io = (cg & (hl_ - 1)) * 8;
+    rt = (m0 + rsub) % p.rope_T;
+    const long to = (long)rt * hd + io, t8 = 8L * hd + io;
+    rc0 = *(const f32x4*)(p.rope_cos + to); rc1 = *(const f32x4*)(p.rope_cos + to + 4);
+    rs0 = *(const f32x4*)(p.rope_sin + to); rs1 = *(const f32x4*)(p.rope_sin + to + 4);
+    k8c0 = *(const f32x4*)(p.rope_cos + t8); k8c1 = *(const f32x4*)(p.rope_cos + t8 + 4);
+    k8s0 = *(const f32x4*)(p.rope_sin + t8); k8s1 = *(const f32x4*)(p.rope_sin + t8 + 4);
+  }
   // the aux operand (gelu' of FC1's pre-activation, 310 MB) is read exactly once: nt + sc1 keeps it out of L1 / low priority in
   // L2 (r04 A/B on dX * gelu', same box: plain 338 us, nt 333, nt + sc1 327-330).  0 = plain loads (A/B variant)
 #ifndef VIT_EPI_AUX_POLICY
@@ -327,25 +342,32 @@ __device__ __forceinline__ void pp_epilogue(f32x4 (&acc)[NI][4], char* scr, cons
       }
       if (FAST == 8 && n0 < p.rope_cols) {  // wave-uniform: this wave's 64 columns are q or k heads
         const int hl = p.rope_dh >> 4;      // lanes per half head: 1, 2 or 4
-        const int t = (int)m % p.rope_T;
-        const long to = (long)t * (p.rope_dh >> 1) + (cg & (hl - 1)) * 8;
-        const f32x4 c0 = *(const f32x4*)(p.rope_cos + to), c1 = *(const f32x4*)(p.rope_cos + to + 4);
-        const f32x4 s0 = *(const f32x4*)(p.rope_sin + to), s1 = *(const f32x4*)(p.rope_sin + to + 4);
         const float sg = (cg & hl) ? 1.f : -1.f;  // first half: x1 cos - x2 sin; second half: x2 cos + x1 sin
+        const f32x4 c0 = rc0, c1 = rc1, s0 = rs0, s1 = rs1;  // this row chunk's angles (the recurrence below)
         float px[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int v = __builtin_bit_cast(int, o[r]);
-          int w;  // the partner lane's value: lane ^ hl inside the 8-lane row segment (ds_swizzle bit mode: and 0x1F, xor hl)
-          if (hl == 4) w = __builtin_amdgcn_ds_swizzle(v, 0x101F);
-          else if (hl == 2) w = __builtin_amdgcn_ds_swizzle(v, 0x081F);
-          else w = __builtin_amdgcn_ds_swizzle(v, 0x041F);
-          px[r] = __builtin_bit_cast(float, w);
-        }
+        for (int r = 0; r < 8; ++r)  // the partner lane's value: lane ^ hl inside the 8-lane row segment (LDS crossbar, no memory)
+          px[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rope_peer, __builtin_bit_cast(int, o[r])));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           o[r] = fmaf(o[r], c0[r], sg * px[r] * s0[r]);
           o[4 + r] = fmaf(o[4 + r], c1[r], sg * px[4 + r] * s1[r]);
+        }
+        // next row chunk of this lane = 8 tokens on: rotate the angles by 8 theta (table row 8); a lane whose token index
+        // wrapped into the next sample reads its row again -- every lane does, behind a WAVE-uniform test, so the loads sit in
+        // one rarely taken block (a 128-row wave tile crosses at most one sample boundary per lane when T >= 128)
+        rt += 8;
+        const bool wrapped = rt >= p.rope_T;
+        if (wrapped) rt -= p.rope_T;
+        {
+          const f32x4 nc0 = rc0 * k8c0 - rs0 * k8s0, ns0 = rs0 * k8c0 + rc0 * k8s0;
+          const f32x4 nc1 = rc1 * k8c1 - rs1 * k8s1, ns1 = rs1 * k8c1 + rc1 * k8s1;
+          rc0 = nc0; rs0 = ns0; rc1 = nc1; rs1 = ns1;
+        }
+        if (__builtin_amdgcn_ballot_w64(wrapped)) {
+          const long to = (long)rt * (p.rope_dh >> 1) + (cg & (hl - 1)) * 8;
+          rc0 = *(const f32x4*)(p.rope_cos + to); rc1 = *(const f32x4*)(p.rope_cos + to + 4);
+          rs0 = *(const f32x4*)(p.rope_sin + to); rs1 = *(const f32x4*)(p.rope_sin + to + 4);
         }
       }
       if (FAST == 3 && p.drop.thr) {
@@ -1239,7 +1261,9 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     // rotary embedding requested: the rotating epilogue where a wave's 64 columns are whole heads, else the caller (gemm_launch)
     // runs the separate pass behind this launch
     if (d->rope_cos) {
-      if (epi5 == 3 && !a.drop.thr && (d->rope_dh == 16 || d->rope_dh == 32 || d->rope_dh == 64) && (d->rope_cols % 64) == 0) epi5 = 8;
+      if (epi5 == 3 && !a.drop.thr && (d->rope_dh == 16 || d->rope_dh == 32 || d->rope_dh == 64) && (d->rope_cols % 64) == 0 &&
+          d->rope_T >= 9)  // the epilogue steps its angles by table row 8
+        epi5 = 8;
     }
     // the bf16 fast epilogues store through 32-bit buffer offsets (raw buffer stores, sc1): outputs past 2 GiB keep the
     // generic epilogue (a clamped descriptor would drop the stores beyond it silently)
