@@ -831,6 +831,73 @@ def make_loadcfg():
     print(f"[loadcfg] wrote {path}: {got['data']}")
 
 
+WANDB_NESTED_YAML = """_wandb:
+  value:
+    cli_version: 0.21.0
+config:
+  value:
+    model: {name: vit, image_size: 4096, patch_size: 32, hidden_size: 32}
+    train: {ep: 3, save: false}
+    data:
+      file_path: ${VIT_GOLD_ROOT}/train.h5
+      param: log_g
+"""
+WANDB_PERKEY_YAML = """_wandb:
+  value: {cli_version: 0.21.0, python_version: 3.10.12}
+model:
+  desc: null
+  value: {name: vit, image_size: 4096, patch_size: 32, hidden_size: 32, num_attention_heads: 2}
+train:
+  value: {ep: 5, batch_size: 64, precision: bf16-mixed}
+loss:
+  value: {name: mae}
+data:
+  value:
+    file_path: ~/spec/train.h5
+    val_path: ${VIT_GOLD_ROOT}/val.h5
+    param: "T_eff,log_g"
+lr:
+  value: 0.001
+tags:
+  value: [a, b]
+project: plain-key
+"""
+
+
+def make_wandbcfg():
+    """`load_config` (src/utils.py:311-359) on the two W&B-export shapes it unwraps -- the real config nested under
+    `config.value`, and every top-level key wrapped as `{value: ...}` with the `_wandb` section dropped -- the reference's own
+    function, environment fixed; tests/golden/wandbcfg.json holds the YAML texts and the dicts it returned."""
+    import json
+    import tempfile
+
+    _import_reference()
+    from src.utils import load_config as ref_load
+
+    env = {"VIT_GOLD_ROOT": "/data/gold", "HOME": "/home/u"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    out = {"env": env, "cases": []}
+    try:
+        for text in (WANDB_NESTED_YAML, WANDB_PERKEY_YAML):
+            with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+                f.write(text)
+            try:
+                out["cases"].append({"yaml": text, "expected": ref_load(f.name)})
+            finally:
+                os.unlink(f.name)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    path = os.path.join(ROOT, "tests", "golden", "wandbcfg.json")
+    with open(path, "w") as fo:
+        json.dump(out, fo, indent=1)
+    print(f"[wandbcfg] wrote {path}: {[sorted(c['expected']) for c in out['cases']]}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -860,6 +927,7 @@ def main():
     make_config()
     make_freeze()
     make_loadcfg()
+    make_wandbcfg()
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
@@ -870,7 +938,7 @@ if __name__ == "__main__":
         torch.manual_seed(0)
         torch.set_num_threads(8)
         for what in sys.argv[1:]:
-            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze, "loadcfg": make_loadcfg,
+            {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze, "loadcfg": make_loadcfg, "wandbcfg": make_wandbcfg,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
              "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
     else:
