@@ -931,6 +931,12 @@ def main():
     # the benchmarked geometries
     make_deep("c3", refvit.named_config("C3"), 4, 71, 72)
     make_deep("c5", refvit.named_config("C5"), 2, 81, 82)
+    # four corners of the reference's sweep space (configs/sweep.yaml:10-21), same recipe
+    for tag, (b, ws) in SWEEP_CASES.items():
+        make_deep(tag, refvit.named_config(tag.upper()), b, ws, ws + 1)
+
+
+SWEEP_CASES = {"s1": (2, 91), "s2": (2, 93), "s3": (2, 95), "s4": (4, 97)}
 
 
 if __name__ == "__main__":
@@ -940,6 +946,8 @@ if __name__ == "__main__":
         for what in sys.argv[1:]:
             {"rope": make_rope, "prep": make_prep, "conv": make_conv, "data": make_data, "opt": make_opt, "evalstats": make_evalstats, "names": make_names, "config": make_config, "freeze": make_freeze, "loadcfg": make_loadcfg, "wandbcfg": make_wandbcfg,
              "c3": lambda: make_deep("c3", refvit.named_config("C3"), 4, 71, 72),
-             "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82)}[what]()
+             "c5": lambda: make_deep("c5", refvit.named_config("C5"), 2, 81, 82),
+             **{t: (lambda t=t: make_deep(t, refvit.named_config(t.upper()), SWEEP_CASES[t][0], SWEEP_CASES[t][1],
+                                          SWEEP_CASES[t][1] + 1)) for t in SWEEP_CASES}}[what]()
     else:
         main()

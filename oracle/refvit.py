@@ -132,6 +132,16 @@ def named_config(name: str) -> RefConfig:
                    num_attention_heads=12, stride_size=256, loss_name="mae"),
         "C5": dict(image_size=147456, patch_size=256, hidden_size=1024, num_hidden_layers=24,
                    num_attention_heads=16, stride_size=256, loss_name="mae"),
+        # four corners of the reference's own sweep space (configs/sweep.yaml:10-21: patch 8..256 x stride 1..32 x hidden
+        # {32, 128} x heads {2, 4, 8} x layers {3, 4, 6} x {SW, CNN} at image_size 4096)
+        "S1": dict(image_size=4096, patch_size=8, hidden_size=32, num_hidden_layers=3,      # T 4090, head_dim 4
+                   num_attention_heads=8, stride_size=1, loss_name="mae"),
+        "S2": dict(image_size=4096, patch_size=64, hidden_size=128, num_hidden_layers=3,    # T 4034, head_dim 64
+                   num_attention_heads=2, stride_size=1, loss_name="mae"),
+        "S3": dict(image_size=4096, patch_size=16, hidden_size=128, num_hidden_layers=4,    # T 2042, head_dim 16, Conv1D
+                   num_attention_heads=8, stride_size=2, proj_fn="CNN", loss_name="mae"),
+        "S4": dict(image_size=4096, patch_size=256, hidden_size=32, num_hidden_layers=6,    # T 122, head_dim 8
+                   num_attention_heads=4, stride_size=32, loss_name="mae"),
     }
     return RefConfig(**table[name])
 

@@ -185,7 +185,10 @@ ATT_SHAPES = [(2, 2, 129, 16), (2, 3, 5, 64), (2, 4, 197, 64), (1, 2, 300, 32), 
               (1, 2, 1025, 16), (1, 1, 640, 64),  # these two: past the resident kernels
               (1, 2, 4034, 16), (1, 1, 4034, 64),  # the stride sweep's longest sequences (configs/sweep.yaml: S = 1 at L = 4096, P = 64)
               (2, 12, 197, 64), (1, 12, 193, 64), (1, 12, 208, 64), (23, 12, 197, 64),  # 12 heads, 192 < T <= 208: the compile-time forms
-              (1, 16, 577, 64), (2, 16, 592, 64)]  # the ViT-L head count and sequence
+              (1, 16, 577, 64), (2, 16, 592, 64),  # the ViT-L head count and sequence
+              # head sizes that are multiples of 4 but not of 8 (heads at 8-byte offsets; configs/sweep.yaml reaches hidden 32 /
+              # 8 heads = 4): short, one tile, and the sweep's longest sequence
+              (2, 8, 122, 4), (1, 8, 64, 4), (1, 8, 4090, 4), (2, 3, 130, 12), (1, 2, 77, 20)]
 
 
 @pytest.mark.parametrize("B,H,T,dh", ATT_SHAPES)
@@ -227,7 +230,7 @@ def extract_attn_mask(vf, dev, B, H, T, dh, drop):
     return mask
 
 
-@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (1, 3, 197, 64), (1, 12, 197, 64)])
+@pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (1, 3, 197, 64), (1, 12, 197, 64), (2, 8, 122, 4), (1, 2, 700, 12)])
 def test_attention_dropout(dev, B, H, T, dh):
     import vit_amd.functional as vf
 
@@ -530,7 +533,7 @@ def test_gemm_x3_epilogues(dev):
 
 
 @pytest.mark.parametrize("B,H,T,dh", [(2, 2, 129, 16), (2, 3, 5, 64), (1, 2, 197, 64), (1, 1, 70, 128), (2, 2, 130, 64),
-                                      (1, 2, 577, 64), (3, 1, 64, 64)])  # head_dim 64: the f32-MFMA kernels; others: one wave per row
+                                      (1, 2, 577, 64), (3, 1, 64, 64), (2, 8, 122, 4), (1, 8, 1030, 4), (1, 3, 130, 12)])  # head_dim 64: the f32-MFMA kernels; others: one wave per row
 def test_attention_f32(dev, B, H, T, dh):
     import vit_amd.functional as vf
 
@@ -631,7 +634,7 @@ def test_gemm_gelu_grad_and_mul_aux(dev, core, dt):
     assert rel(dU, pre.grad) < (8e-3 if dt == torch.bfloat16 else 3e-5)
 
 
-@pytest.mark.parametrize("B,H,T,dh", [(3, 2, 129, 16), (4, 3, 197, 64), (2, 4, 50, 32)])
+@pytest.mark.parametrize("B,H,T,dh", [(3, 2, 129, 16), (4, 3, 197, 64), (2, 4, 50, 32), (2, 8, 122, 4)])
 def test_attention_bwd_fused_colsum(dev, B, H, T, dh):
     """vit_attention_bwd_colsum: the per-wave column sums the resident kernels emit, reduced over the batch, must equal
     vit_colsum over the stored dqkv (same bf16-rounded values, f32 sums), with and without dropout, for 1 and 2

@@ -25,7 +25,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = {"c3": ("C3", 4), "c5": ("C5", 2)}
+CASES = {"c3": ("C3", 4), "c5": ("C5", 2),
+         # four corners of the reference's own sweep space (configs/sweep.yaml:10-21, image_size 4096), same fixture recipe:
+         # s1 = patch 8 / stride 1 / hidden 32 / 8 heads (T 4090, head_dim 4), s2 = patch 64 / stride 1 / hidden 128 / 2 heads
+         # (T 4034, head_dim 64: the tiled attention kernels inside a model, unpadded row count 8068), s3 = Conv1D tokenizer,
+         # patch 16 / stride 2 / hidden 128 / 8 heads (T 2042, head_dim 16), s4 = patch 256 / stride 32 / hidden 32 / 4 heads
+         # (T 122, head_dim 8, 6 layers)
+         "s1": ("S1", 2), "s2": ("S2", 2), "s3": ("S3", 2), "s4": ("S4", 4)}
+ALL = ["c3", "c5", "s1", "s2", "s3", "s4"]
 _cache = {}
 
 
@@ -79,8 +86,8 @@ def build(o, dev, precision):
     return model.to(dev).eval()
 
 
-@pytest.mark.parametrize("tag", ["c3", "c5"])
-@pytest.mark.parametrize("precision", ["bf16-mixed", "32"])
+@pytest.mark.parametrize("precision", ["bf16-mixed", "32"])  # the top decorator varies fastest: one oracle run per tag
+@pytest.mark.parametrize("tag", ALL)
 def test_deep_eval_forward(dev, tag, precision):
     o = oracle_run(tag)
     g, rc = o["g"], o["rc"]
@@ -152,8 +159,8 @@ def _check_grads(model, o, precision, tag):
           f"the reference's own bf16-autocast gradients: worst {ref_bf16:.2e}")
 
 
-@pytest.mark.parametrize("tag", ["c3", "c5"])
-@pytest.mark.parametrize("precision", ["bf16-mixed", "32"])
+@pytest.mark.parametrize("precision", ["bf16-mixed", "32"])  # the top decorator varies fastest: one oracle run per tag
+@pytest.mark.parametrize("tag", ALL)
 def test_deep_gradients(dev, tag, precision):
     o = oracle_run(tag)
     model = build(o, dev, precision)

@@ -63,6 +63,26 @@ __device__ __forceinline__ int tile_off(int r, int c) {
   return r * (DH * 2) + ((c ^ swz<DH>(r)) << 4);
 }
 
+// 8 bf16 of a head's row from column `col` (a multiple of 8), zero past the head size.  A head size that is a multiple of 4
+// but not of 8 (the reference's sweep reaches hidden 32 / 8 heads = 4, configs/sweep.yaml:13-18) puts heads at 8-byte offsets
+// and ends them in half a chunk: those take 8-byte loads; every other shape keeps its single 16-byte load.
+__device__ __forceinline__ i32x4 ld_head8(const short* p, int col, int dh) {
+  i32x4 v = {0, 0, 0, 0};
+  if ((dh & 7) == 0) {
+    if (col < dh) v = *(const i32x4*)(p + col);
+    return v;
+  }
+  if (col < dh) {
+    const i32x2 h = *(const i32x2*)(p + col);
+    v[0] = h[0]; v[1] = h[1];
+  }
+  if (col + 4 < dh) {
+    const i32x2 h = *(const i32x2*)(p + col + 4);
+    v[2] = h[0]; v[3] = h[1];
+  }
+  return v;
+}
+
 // cooperative load of rows [row0, row0+64) x [0, DH) of a strided bf16 matrix into an LDS image (zero fill outside)
 template <int DH>
 __device__ __forceinline__ void load_tile(char* img, const short* g, long ld, int row0, int nrows, int dh, int tid) {
@@ -73,7 +93,7 @@ __device__ __forceinline__ void load_tile(char* img, const short* g, long ld, in
     const int r = q / CPR, c = q % CPR;
     const int row = row0 + r;
     i32x4 v = {0, 0, 0, 0};
-    if (row < nrows && c * 8 < dh) v = *(const i32x4*)(g + (long)row * ld + c * 8);
+    if (row < nrows) v = ld_head8(g + (long)row * ld, c * 8, dh);
     *(i32x4*)(img + tile_off<DH>(r, c)) = v;
   }
 }
@@ -102,7 +122,7 @@ __device__ __forceinline__ void load_own(bf16x8 (&f)[DH / 32], const short* g, l
   for (int s = 0; s < DH / 32; ++s) {
     const int col = s * 32 + lg * 8;
     i32x4 v = {0, 0, 0, 0};
-    if (r0 + l15 < nrows && col < dh) v = *(const i32x4*)(g + (long)(r0 + l15) * ld + col);
+    if (r0 + l15 < nrows) v = ld_head8(g + (long)(r0 + l15) * ld, col, dh);
     f[s] = __builtin_bit_cast(bf16x8, v);
   }
 }
@@ -259,11 +279,11 @@ __global__ __launch_bounds__(AW * 64) void attn_bwd_dq_kernel(AttnArgs p) {
     for (int s = 0; s < DH / 32; ++s) {
       const int col = s * 32 + lg * 8;
       if (q < T && col < dh) {
-        const bf16x8 o = *(const bf16x8*)(ob + (long)q * ldc + col);
+        const bf16x8 o = __builtin_bit_cast(bf16x8, ld_head8(ob + (long)q * ldc, col, dh));
 #pragma unroll
         for (int e = 0; e < 8; ++e) del += bf2f(o[e]) * bf2f(dof[s][e]);
         if (p.ctx_lo) {
-          const bf16x8 ol = *(const bf16x8*)(p.ctx_lo + (ob - p.ctx) + (long)q * ldc + col);
+          const bf16x8 ol = __builtin_bit_cast(bf16x8, ld_head8(p.ctx_lo + (ob - p.ctx) + (long)q * ldc, col, dh));
 #pragma unroll
           for (int e = 0; e < 8; ++e) del += bf2f(ol[e]) * bf2f(dof[s][e]);
         }
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const short* __restrict
   for (int k = lane; k < T; k += 64) {
     float s = 0.f;
     for (int d = 0; d < dh; d += 8) {
-      const bf16x8 x = *(const bf16x8*)(qp + d), y = *(const bf16x8*)(kp + (long)k * ld + d);
+      const bf16x8 x = __builtin_bit_cast(bf16x8, ld_head8(qp, d, dh)), y = __builtin_bit_cast(bf16x8, ld_head8(kp + (long)k * ld, d, dh));
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
     }
@@ -1918,6 +1938,7 @@ int g_attn_res_max_t = RES_MAX_T;  // vit_set_option("attn_res_max_t"): larger T
 int g_attn_split = 2;  // vit_set_option("attn_split"): workgroups per (batch, head) in the resident kernels
 
 static bool res_fits(int T, int dh) {  // the dK/dV kernel's LDS: the staged rows of Q and dO + three f32 rows of statistics
+  if (dh & 7) return false;  // 8-byte head offsets: the tiled kernels (ld_head8); the resident ones stage 16-byte pieces
   const size_t dhp = dh <= 32 ? 32 : 64, rows = (T + 15) & ~15, rows_st = (T + 63) & ~63;
   return 2 * rows * dhp * 2 + 3 * rows_st * 4 <= 160 * 1024;
 }
@@ -2447,7 +2468,7 @@ static int launch_attn32(int which, Attn32Args& a, hipStream_t st) {
 
 static int check_attn(const char* fn, int B, int H, int T, int dh, float p) {
   VIT_CHECK(B > 0 && H > 0 && T > 0 && dh > 0, VIT_ERR_ARG, "%s: B=%d H=%d T=%d dh=%d", fn, B, H, T, dh);
-  VIT_CHECK((dh % 8) == 0 && dh <= 128, VIT_ERR_UNSUPPORTED, "%s: head dim %d (need a multiple of 8, <= 128)", fn, dh);
+  VIT_CHECK((dh % 4) == 0 && dh <= 128, VIT_ERR_UNSUPPORTED, "%s: head dim %d (need a multiple of 4, <= 128)", fn, dh);
   VIT_CHECK(p >= 0.f && p < 1.f, VIT_ERR_ARG, "%s: dropout_p out of [0,1)", fn);
   return VIT_OK;
 }

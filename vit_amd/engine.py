@@ -135,6 +135,15 @@ class ViTEngine:
                              f"Choose from: 'rope', 'learned', 'none', or None")  # embedding.py:74
         if cfg.proj_fn not in ("SW", "C1D", "CNN"):
             raise ValueError(f"Unsupported proj_fn '{cfg.proj_fn}'")  # embedding.py:44
+        # what the kernels take, said at construction instead of as a VIT_ERR_UNSUPPORTED in the middle of a step.  The
+        # reference's own sweep (configs/sweep.yaml:10-21) reaches head_dim 4 (hidden 32 / 8 heads) and T = 4090 (patch 8,
+        # stride 1): both run in both precisions.
+        if cfg.hidden_size % cfg.num_attention_heads:
+            raise ValueError(f"The hidden size {cfg.hidden_size} is not a multiple of the number of attention heads "
+                             f"{cfg.num_attention_heads}.")  # HF ViTSelfAttention.__init__
+        if cfg.head_dim % 4 or cfg.head_dim > 128 or cfg.hidden_size % 8 or cfg.patch_size % 8:
+            raise ValueError(f"vit_amd kernels need head_dim % 4 == 0 and <= 128, hidden_size % 8 == 0, patch_size % 8 == 0 "
+                             f"(got head_dim {cfg.head_dim}, hidden_size {cfg.hidden_size}, patch_size {cfg.patch_size})")
         self.cfg = cfg
         self.loss_name, self.loss_kind = resolved_loss(cfg.task_type, loss_name)
         self.layout = ParamLayout(cfg)
@@ -177,6 +186,9 @@ class ViTEngine:
                              f"scaling); use '32' or 'bf16-mixed'")
         else:
             raise ValueError(f"Unsupported precision '{precision}'")
+        if mode == "f32" and self.cfg.seq_len > 4096:
+            raise ValueError(f"precision '{precision}': the fp32 attention kernels keep a score row in the LDS and take at most "
+                             f"4096 tokens (this model has {self.cfg.seq_len}); use 'bf16-mixed'")
         if mode != self.precision:
             self.precision = mode
             self._drop_arenas()
@@ -336,6 +348,9 @@ class ViTEngine:
             raise ValueError(f"pixel_values must be [batch, {c.image_size}], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise VitError("pixel_values must live on the GPU")
+        if self.precision == "f32" and c.seq_len > 4096:
+            raise ValueError(f"precision '32': the fp32 attention kernels take at most 4096 tokens (this model has "
+                             f"{c.seq_len}); use train.precision 'bf16-mixed'")
         x = x.contiguous().to(torch.float32)
         B = x.shape[0]
         self._gen += 1
