@@ -936,7 +936,7 @@ def main():
         make_deep(tag, refvit.named_config(tag.upper()), b, ws, ws + 1)
 
 
-SWEEP_CASES = {"s1": (2, 91), "s2": (2, 93), "s3": (2, 95), "s4": (4, 97)}
+SWEEP_CASES = {"s1": (2, 91), "s2": (4, 93), "s3": (8, 95), "s4": (16, 97)}
 
 
 if __name__ == "__main__":

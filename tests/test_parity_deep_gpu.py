@@ -31,7 +31,7 @@ CASES = {"c3": ("C3", 4), "c5": ("C5", 2),
          # (T 4034, head_dim 64: the tiled attention kernels inside a model, unpadded row count 8068), s3 = Conv1D tokenizer,
          # patch 16 / stride 2 / hidden 128 / 8 heads (T 2042, head_dim 16), s4 = patch 256 / stride 32 / hidden 32 / 4 heads
          # (T 122, head_dim 8, 6 layers)
-         "s1": ("S1", 2), "s2": ("S2", 2), "s3": ("S3", 2), "s4": ("S4", 4)}
+         "s1": ("S1", 2), "s2": ("S2", 4), "s3": ("S3", 8), "s4": ("S4", 16)}
 ALL = ["c3", "c5", "s1", "s2", "s3", "s4"]
 _cache = {}
 
@@ -106,7 +106,11 @@ def test_deep_eval_forward(dev, tag, precision):
     e_arow = max(rel(out.attentions[0].reshape(-1, T)[arow], g["attn0_rows"]),
                  rel(out.attentions[-1].reshape(-1, T)[arow], g["attn_last_rows"]))
     e_fix_logits = rel(out.logits, g["logits"])
-    e_ref_bf16 = rel(g["bf16_logits"], g["logits"])
+    # yardstick of the bf16 gate: the reference's own bf16-autocast error on the logits -- a relative error over `batch`
+    # numbers, i.e. noisy for the 2..16-sample sweep cases (s1: 6.9e-4 over two logits while its hidden states sit at
+    # 5.6e-3) -- so never less than its error on the sampled rows of the final LayerNorm output the logits are read from
+    e_ref_last = rel(g["bf16_last_rows"], g["last_rows"])
+    e_ref_bf16 = max(rel(g["bf16_logits"], g["logits"]), e_ref_last)
     print(f"[{tag} {precision}] hidden states max {max(errs):.2e} (layer {int(np.argmax(errs))}), attention {e_att:.2e}, "
           f"logits {e_logits:.2e}, loss {e_loss:.2e}; vs fixture: rows {e_rows:.2e}, attn rows {e_arow:.2e}, "
           f"logits {e_fix_logits:.2e} (reference's own bf16 autocast: {e_ref_bf16:.2e})")
