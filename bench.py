@@ -136,7 +136,7 @@ def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, medi
     # reserve_cus sweep, all-reduce schedule
     sweep, best = [], (median_ms, args.reserve_cus)
     for rc in (0, 8, 16, 32):
-        _cabi.set_option("reserve_cus", rc)
+        trainer.set_reserve_cus(module, rc)
         on = run(n_probe)
         set_exchange(None)
         off = run(n_probe)
@@ -153,7 +153,7 @@ def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, medi
         z = ddp_mod.make_reducer("zero1", eng, grad_dtype="fp32", max_bucket_elems=getattr(trainer, "max_bucket_elems", 64 << 20))
         zs = []
         for rc in sorted({0, best[1]}):
-            _cabi.set_option("reserve_cus", rc)
+            trainer.set_reserve_cus(module, rc)
             set_exchange(z)
             on = run(n_probe)
             zs.append({"reserve_cus": rc, "ms_per_step": round(on, 3),
@@ -162,7 +162,7 @@ def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, medi
     except Exception as e:  # noqa: BLE001
         out["zero1_error"] = f"{type(e).__name__}: {e}"
     set_exchange(red)
-    _cabi.set_option("reserve_cus", args.reserve_cus)
+    trainer.set_reserve_cus(module, args.reserve_cus)
     # strong scaling at a global batch of 256
     B = batch[0].shape[0]
     if not args.global_batch and 256 % world == 0 and 256 // world != B and 256 // world <= B:
@@ -173,6 +173,121 @@ def comm_probe(args, trainer, module, eng, red, batch, barrier, dev, world, medi
         ms = run(n_probe, small)
         out["strong_scaling"] = {"global_batch": 256, "per_gpu_batch": bs, "ms_per_step": round(ms, 3),
                                  "images_per_s": round(256 / (ms * 1e-3), 2)}
+    return out
+
+
+def build_run(workload, B, precision, dev, rank, use_graph=False, quiet=True):
+    """Module + trainer (optimizer, exchange) + one synthetic batch resident in HBM for a named workload (SURVEY 8d inputs:
+    generator seed 1234 + rank, flux ~ N(0,1), error = 0.1 |N(0,1)|, labels ~ U[0,1); model seed 42, scripts/run.py:22)."""
+    import contextlib
+
+    import torch
+
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    L, P, D, layers, heads, _ = WORKLOADS[workload]
+    config = {
+        "model": dict(name="vit", task_type="reg", image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
+                      num_attention_heads=heads, stride_size=P, proj_fn="SW"),
+        "train": dict(batch_size=B, ep=1, precision=precision, hip_graph=use_graph),
+        "loss": {"name": "mae"},
+        "opt": {"type": "AdamW", "lr": 1e-3},
+        "data": {"param": "log_g"},
+        "noise": {"noise_level": 0},
+    }
+    seed_everything(42)
+    with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
+        module = ViTLModule(config=config)
+    trainer = Trainer(config["train"], device=dev, verbose=False)
+    trainer._setup(module)
+    module.train()
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    flux = torch.randn((B, L), generator=g)
+    error = 0.1 * torch.randn((B, L), generator=g).abs()
+    labels = torch.rand((B,), generator=g)
+    host = (flux, error, labels)
+    batch = tuple(t.to(dev) for t in host)
+    return module, trainer, batch, host
+
+
+def median(xs):
+    srt = sorted(xs)
+    return srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+
+
+def time_steps(trainer, module, batches, n, warmup):
+    """Median per-step hipEvent time (ms) of `n` optimisation steps after `warmup` untimed ones; `batches` is an iterator."""
+    import torch
+
+    for i in range(warmup):
+        trainer.training_step(module, next(batches), i)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for i in range(n):
+        trainer.training_step(module, next(batches), i)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return median([ev[i].elapsed_time(ev[i + 1]) for i in range(n)])
+
+
+def secondary_workloads(dev, rank, precision):
+    """BASELINE.json's other single-GPU configurations, timed in the same process after the headline so that they are
+    driver-observed too: C5 = ViT-L/16 384^2 (B 32) and C2 = ViT-Tiny/16 32x32 (B 64; launch-bound: a
+    correctness configuration).  Median per-step hipEvent time of the same full optimisation step."""
+    import itertools
+
+    out = {}
+    for name, steps, warmup in (("vit_l16_384", 16, 4), ("vit_tiny16_32", 30, 10)):
+        L, P, D, layers, heads, B = WORKLOADS[name]
+        t0 = time.perf_counter()
+        module, trainer, batch, _ = build_run(name, B, precision, dev, rank)
+        ms = time_steps(trainer, module, itertools.repeat(batch), steps, warmup)
+        flop_img = train_flop_per_image(L, P, D, layers, 4 * D)
+        out[name] = {"value": round(B / (ms * 1e-3), 2), "unit": "images/s", "ms_per_step": round(ms, 3), "steps": steps,
+                     "warmup": warmup, "batch": B, "train_gflop_per_image": round(flop_img / 1e9, 3),
+                     "step_frac": round(B / (ms * 1e-3) * flop_img / PEAK_BF16_DENSE, 4),
+                     "wall_s": round(time.perf_counter() - t0, 1)}
+        log(f"secondary {name}: {out[name]}")
+        del module, trainer, batch
+    return out
+
+
+def input_pipeline_probe(trainer, module, host, dev, B, steps, device_ms):
+    """What `Trainer.fit` pays for its inputs at this workload (SURVEY 8a16 / 8d 'variant produced on host + H2D'): the same
+    optimisation steps fed by vit_amd.data.SpecLoader from a HOST-resident split of 8 x B spectra -- (a) placement 'host': a
+    worker thread gathers each shuffled batch into pinned memory and a copy stream moves it one to two batches ahead; (b)
+    placement 'device': the split uploaded once, a batch = a row gather in HBM.  Reference: DataLoader(shuffle, pin_memory,
+    persistent_workers) -> batch.to(device), src/basemodule.py:76-85.  `value` (inputs resident) is not touched by this."""
+    import torch
+
+    from vit_amd.data import SpecDataset, SpecLoader
+
+    flux, error, labels = host
+    reps = 8
+    ds = SpecDataset(torch.cat([flux.roll(i, 0) for i in range(reps)]).abs_(), torch.cat([error] * reps),
+                     torch.cat([labels] * reps), task="reg", stage="train")
+    out = {"split_rows": len(ds), "split_mbytes": round(ds.flux.numel() * 4 / 1e6, 1), "steps": steps,
+           "device_resident_batch_ms_per_step": round(device_ms, 3)}
+
+    def stream(loader):
+        e = 0
+        while True:
+            loader.set_epoch(e)
+            yield from loader
+            e += 1
+
+    for mode in ("host", "device"):
+        loader = SpecLoader(ds, B, shuffle=True, placement=mode).bind(dev)
+        it = stream(loader)
+        ms = time_steps(trainer, module, it, steps, 3)
+        it.close()
+        out[f"{mode}_ms_per_step"] = round(ms, 3)
+        out[f"{mode}_images_per_s"] = round(B / (ms * 1e-3), 2)
+        out[f"{mode}_vs_resident_batch"] = round(device_ms / ms, 4)
+    out["h2d_bytes_per_step_host"] = int(B * (flux.shape[1] + 1) * 4)
+    out["note"] = "error tensor not shipped (noise_level 0: SURVEY 8a16); the reference ships 2*B*L*4 bytes per step"
     return out
 
 
@@ -204,6 +319,12 @@ def main():
     ap.add_argument("--no-gc-freeze", action="store_true",
                     help="diagnostic: leave the start-up heap in the cyclic GC's young generations (shows the pause the freeze removes)")
     ap.add_argument("--no-comm-probe", action="store_true", help="N > 1: skip the exchange-off steps and the bare all-reduce timing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C5 / C2 lines timed after the headline (N = 1 only)")
+    ap.add_argument("--input", default="device", choices=["device", "host"],
+                    help="device (default; the contract's `value`): the batch is resident in HBM.  host: every timed step takes its "
+                         "batch from a host-resident split through SpecLoader's pinned / copy-stream staging (PCIe-inclusive; "
+                         "reported as such, never the headline).  The default run measures both after `value` (input_pipeline)")
+    ap.add_argument("--no-input-probe", action="store_true", help="skip the host-staged / device-gather input measurements")
     ap.add_argument("--launch-check", action="store_true",
                     help="rank plumbing only (no GPU): every rank joins a gloo group, rank 0 prints {world, sum of ranks}")
     args = ap.parse_args()
@@ -242,56 +363,16 @@ def main():
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of the {world} ranks")
         B = args.global_batch // world
-    config = {
-        "model": dict(name="vit", task_type="reg", image_size=L, patch_size=P, hidden_size=D, num_hidden_layers=layers,
-                      num_attention_heads=heads, stride_size=P, proj_fn="SW"),
-        "train": dict(batch_size=B, ep=1, precision=args.precision),
-        "loss": {"name": "mae"},
-        "opt": {"type": "AdamW", "lr": 1e-3},
-        "data": {"param": "log_g"},
-        "noise": {"noise_level": 0},
-    }
     autotune = args.reserve_cus < 0 and exchanging
     if args.reserve_cus < 0:
         args.reserve_cus = 0
-    if args.reserve_cus:
-        _cabi.set_option("reserve_cus", args.reserve_cus)
-    seed_everything(42)  # scripts/run.py:22,28
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):  # the builders print like the reference's do; stdout carries ONE JSON line
-        module = ViTLModule(config=config)
     use_graph = not exchanging and args.graph and not args.no_graph
-    config["train"]["hip_graph"] = use_graph
-    trainer = Trainer(config["train"], device=dev, verbose=False)
-    trainer._setup(module)
-    module.train()
+    module, trainer, batch, host = build_run(args.workload, B, args.precision, dev, rank, use_graph=use_graph)
+    if args.reserve_cus:
+        trainer.set_reserve_cus(module, args.reserve_cus)
     if args.no_overlap or use_graph:
         module.model.engine.overlap_dw = False
-
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    flux = torch.randn((B, L), generator=g).to(dev)
-    error = (0.1 * torch.randn((B, L), generator=g).abs()).to(dev)
-    labels = torch.rand((B,), generator=g).to(dev)
-    batch = (flux, error, labels)
-
-    # ---- per-GEMM event brackets (the launches all go to torch's current stream, which the events are recorded on)
-    records = []
-    if not args.no_kernel_timing:
-        orig_gemm = vf.gemm
-
-        lib = _cabi.load()
-
-        def timed_gemm(a, b, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_gemm(a, b, **kw)
-            e1.record()
-            if timing_on[0]:
-                records.append((lib.vit_last_gemm_kernel().decode(), kw["M"], kw["N"], kw["K"], e0, e1))
-            return out
-
-        timing_on = [False]
-        vf.gemm = timed_gemm
+    lib = _cabi.load()
 
     def barrier():
         torch.cuda.synchronize()
@@ -299,9 +380,30 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    import itertools
+
+    batch_iter = itertools.repeat(batch)
+    if args.input == "host":
+        # PCIe-inclusive variant: every step's batch is gathered from a host-resident split into pinned memory by the loader's
+        # worker thread and copied on its copy stream (vit_amd/data.py: _Stager).  Never the headline (`value` = resident inputs).
+        from vit_amd.data import SpecDataset, SpecLoader
+
+        ds = SpecDataset(torch.cat([host[0].roll(i, 0) for i in range(8)]).abs_(), torch.cat([host[1]] * 8),
+                         torch.cat([host[2]] * 8), task="reg", stage="train")
+        loader = SpecLoader(ds, B, shuffle=True, placement="host").bind(dev)
+
+        def stream_batches():
+            e = 0
+            while True:
+                loader.set_epoch(e)
+                yield from loader
+                e += 1
+
+        batch_iter = stream_batches()
+
     tuned = None
     if autotune:
-        tuned = trainer.autotune_reserve_cus(module, batch)
+        tuned = trainer.autotune_reserve_cus(module, batch, restore=False)  # these steps are warm-up here
         args.reserve_cus = trainer.reserve_cus
         if rank == 0:
             log(f"reserve_cus autotune (ms per step): {tuned} -> {args.reserve_cus}")
@@ -309,7 +411,7 @@ def main():
         log(f"model on {dev}, {sum(p.numel() for p in module.parameters())} parameters; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         try:
-            trainer.training_step(module, batch, i)
+            trainer.training_step(module, next(batch_iter), i)
         except Exception as e:  # noqa: BLE001 - the harness must still produce its line: capture trouble -> eager launches
             if not (use_graph and i == 0):
                 raise
@@ -352,7 +454,7 @@ def main():
     marks[0].record()
     th = t0
     for i in range(args.steps):
-        loss = trainer.training_step(module, batch, i)
+        loss = trainer.training_step(module, next(batch_iter), i)
         marks[i + 1].record()
         tn = time.perf_counter()
         host_ms.append((tn - th) * 1e3)
@@ -361,25 +463,45 @@ def main():
     dt = time.perf_counter() - t0
     gc.callbacks.remove(gc_cb)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    # The per-GEMM HIP-event brackets (two event records around each of ~170 vit_gemm calls per step) cost 2-4 % of a
-    # step, so `value` comes from the clean region above and the kernel-level roofline from an instrumented repetition
-    # of the same steps right after it (same state, same inputs; `roofline.instrumented_ms_per_step` says what they took).
+    # The per-GEMM HIP-event brackets (two event records around each of ~170 vit_gemm calls per step) are installed ONLY for
+    # this repetition of the same steps (same state, same inputs): the clean region above ran the library's own vf.gemm, so
+    # `value` carries no event record beyond the K + 1 step marks.  `roofline.instrumented_ms_per_step` is what the bracketed
+    # steps took -- on ONE stream (each GEMM alone on the GPU: with the weight-gradient GEMMs on their second stream a bracket
+    # would time two kernels sharing the CUs), so its distance to `ms_per_step` = event cost - what the second stream buys.
+    records = []
     dt_inst, n_inst = None, 0
     if not args.no_kernel_timing:
         n_inst = min(args.steps, 20)
-        timing_on[0] = True
+        orig_gemm = vf.gemm
+
+        def timed_gemm(a, b, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_gemm(a, b, **kw)
+            e1.record()
+            records.append((lib.vit_last_gemm_kernel().decode(), kw["M"], kw["N"], kw["K"], e0, e1))
+            return out
+
         trainer.use_graph = False  # the per-GEMM event brackets need the eager launches
-        # ... and each GEMM alone on the GPU: with the weight-gradient GEMMs on their second stream a bracket would time two
-        # kernels sharing the CUs, not a launch
         overlap_was = module.model.engine.overlap_dw
         module.model.engine.overlap_dw = False
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(n_inst):
-            trainer.training_step(module, batch, i)
-        barrier()
-        dt_inst = time.perf_counter() - t1
-        timing_on[0] = False
+        vf.gemm = timed_gemm
+        try:
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n_inst):
+                trainer.training_step(module, batch, i)
+            barrier()
+            dt_inst = time.perf_counter() - t1
+        finally:
+            vf.gemm = orig_gemm
+        # the same one-stream steps WITHOUT the brackets: instrumented - this = what the ~340 event records per step cost
+        one_stream_ms = None
+        if not exchanging:
+            try:
+                one_stream_ms = time_steps(trainer, module, itertools.repeat(batch), min(n_inst, 10), 1)
+            finally:
+                module.model.engine.overlap_dw = overlap_was
         module.model.engine.overlap_dw = overlap_was
     if exchanging:  # MAX over ranks, of the region and of every step
         t = torch.tensor([dt] + step_ms, dtype=torch.float64, device=dev)
@@ -466,9 +588,29 @@ def main():
             "all_gemm_tflops": round(gemm_fl / (gemm_ms * 1e-3) / 1e12, 1),
             "all_gemm_share_of_step_time": round(gemm_ms / (dt_inst * 1e3), 3),
             "instrumented_steps": n_inst, "instrumented_ms_per_step": round(dt_inst / n_inst * 1e3, 3),
+            "one_stream_uninstrumented_ms_per_step": None if one_stream_ms is None else round(one_stream_ms, 3),
+            "event_cost_ms_per_step": None if one_stream_ms is None else round(dt_inst / n_inst * 1e3 - one_stream_ms, 3),
             "step_tflops": round(value / world * flop_img / 1e12, 2),
             "step_frac": round(value / world * flop_img / PEAK_BF16_DENSE, 4),
         }
+
+    # ---- N = 1: what fit() pays for its inputs, and the other single-GPU configurations, in this same driver-observed run
+    input_pipeline, secondary = None, None
+    if world == 1 and not exchanging:
+        if not args.no_input_probe and args.input == "device":
+            try:
+                input_pipeline = input_pipeline_probe(trainer, module, host, dev, B, min(args.steps, 12), median_ms)
+                log(f"input pipeline: {input_pipeline}")
+            except Exception as e:  # noqa: BLE001 - extra evidence; `value` above is already measured
+                input_pipeline = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_secondary and args.workload == "vit_b16_224" and not args.batch:
+            del batch, batch_iter
+            module.model.engine._drop_arenas()
+            try:
+                secondary = secondary_workloads(dev, rank, args.precision)
+            except Exception as e:  # noqa: BLE001
+                secondary = {"error": f"{type(e).__name__}: {e}"}
+    gc.unfreeze()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not exchanging and not args.no_cpu_baseline:
@@ -486,6 +628,7 @@ def main():
                        "heap_frozen": not args.no_gc_freeze},
             "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
+            "input": "resident in HBM" if args.input == "device" else "host-resident split, pinned staging + copy stream per step (PCIe-inclusive)",
             "dtype": "bf16" if args.precision == "bf16-mixed" else "f32 (split-bf16 x3 MFMA)", "data": "synthetic",
             "config": {"workload": f"{args.workload}: flux[{B},{L}] f32/GPU, patch {P}, {L // P}+1 tokens, hidden {D}, "
                                    f"{heads} heads, {layers} layers, MLP {F}; fwd+bwd+clip0.5+AdamW, dropout 0.1 on",
@@ -494,7 +637,8 @@ def main():
                        "launch": "one hipGraph replay per step" if use_graph else
                        ("eager launches, weight-gradient GEMMs on a second HIP stream" if module.model.engine.overlap_dw
                         else "eager launches, one stream")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "comm": comm, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary, "input_pipeline": input_pipeline,
+            "comm": comm, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     if exchanging:

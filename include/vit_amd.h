@@ -14,8 +14,9 @@
  *     of 8 elements (of an f32 one: 4), checked on the host before any launch (VIT_ERR_ARG otherwise);
  *   - dropout masks are a pure function of (seed, site, row, col): forward and backward regenerate them, nothing is
  *     stored;
- *   - state: the handle (workspace pointer, optional per-step state pointer) and the process-wide kernel-selection
- *     knobs of vit_set_option; nothing else persists between calls.
+ *   - state: the handle (workspace pointer, optional per-step state pointer, launch geometry: vit_handle_set_option) and
+ *     the process-wide kernel-selection knobs of vit_set_option (A/B switches between bit-identical kernel forms); nothing
+ *     else persists between calls.
  */
 #ifndef VIT_AMD_H_
 #define VIT_AMD_H_
@@ -82,6 +83,12 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   --defs ... --tag ... -- never a switch of this library: results are meaningless in such a build.)
  *                Returns VIT_ERR_ARG for an unknown name. */
 int vit_set_option(const char* name, int value);
+/* Per-handle launch geometry: what changes HOW MANY workgroups a call through this handle launches belongs to the handle, so
+ * that two engines of one process (training + evaluation, an engine's second-stream handle) do not depend on the order
+ * in which they were configured.  "reserve_cus": -1 (default) = follow the process-wide value above, 0 .. 128 = this handle's
+ * own.  The remaining vit_set_option knobs select between bit-identical kernel forms for A/B runs and stay process-wide.
+ * Reference: none (Lightning's 'ddp' overlaps NCCL with kernels that do not own whole SMs, src/hardware_utils.py:86-95). */
+int vit_handle_set_option(vit_handle h, const char* name, int value);
 
 /* Per-step state in device memory, for a training step captured as a hipGraph (HIP streams and graphs instead of a tracing
  * compiler: kernel arguments are frozen at capture, so what changes from step to step must be read from memory).

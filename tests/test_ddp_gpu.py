@@ -117,6 +117,31 @@ def test_checkpoint_resume_under_exchange(tmp_path, exchange):
     assert float((r[0]["part"]["m"] != 0).float().mean()) > 0.9
 
 
+def test_fit_with_reserve_cus_auto_equals_fixed_value(tmp_path):
+    """ADVICE r4 (medium) / VERDICT r4 #4 ii: `train.ddp_reserve_cus: auto` times 16 real optimisation steps on the first batch
+    before epoch 0.  They must leave NO trace: parameters, AdamW moments and step count, the per-step learning-rate scheduler,
+    global_step, the dropout stream and torch's generator (noise seeds) are snapshotted and restored, the peeked batch is
+    handed back to a one-shot iterator -- so the run equals, bit for bit, the run with the chosen value fixed in the config
+    (the reference's DDP does nothing before epoch 0: src/basemodule.py:226-251).  Two ranks sharing the GPU over gloo."""
+    from vit_amd.launch import launch_ranks
+
+    out = tmp_path / "autotune"
+    out.mkdir()
+    child = os.path.join(ROOT, "tests", "_autotune_child.py")
+    assert launch_ranks(2, child, [str(out), "bf16-mixed"], extra_env={"VIT_DIST_BACKEND": "gloo"}) == 0
+    r = [torch.load(out / f"rank{k}.pt", weights_only=True) for k in range(2)]
+    for k in range(2):
+        for variant in ("loader", "one_shot"):
+            a, f = r[k][variant]["auto"], r[k][variant]["fixed"]
+            assert a["reserve_cus"] in (0, 8, 16, 32) and a["reserve_cus"] == f["reserve_cus"]
+            steps = 3 * (1 if variant == "one_shot" else 2)  # 96 samples / 2 ranks / 16 per batch, per epoch
+            assert a["global_step"] == f["global_step"] == a["opt_step"] == a["dropout_step"] == steps, (variant, a["global_step"])
+            assert a["lr"] == f["lr"] and a["loss"] == f["loss"] and torch.equal(a["rng"], f["rng"])
+            for name in ("params", "m", "v"):
+                assert torch.equal(a[name], f[name]), (k, variant, name)
+    assert torch.equal(r[0]["loader"]["auto"]["params"], r[1]["loader"]["auto"]["params"])
+
+
 def test_two_ranks_at_vit_b_geometry(tmp_path):
     """the N > 1 path at the BENCHMARKED geometry (12 x 768, T = 197: C3 / C4), four samples per rank, two
     ranks sharing the GPU over gloo, bf16-mixed with the weight-gradient GEMMs on the second stream: the 14 buckets are the real

@@ -57,6 +57,7 @@ _PROTOS = {
     "vit_destroy": [_P],
     "vit_set_workspace": [_P, _P, _SZ],
     "vit_set_option": [C.c_char_p, _I],
+    "vit_handle_set_option": [_P, C.c_char_p, _I],
     "vit_step_state_bind": [_P, _P],
     "vit_step_advance": [_P, _U64, _F, _F, _P],
     "vit_adamw_step_dyn": [_P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _P, _F, _P],
@@ -163,6 +164,10 @@ class Handle:
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{self.device_index}")
         check(self.lib.vit_set_workspace(self.h, self._ws.data_ptr(), nbytes), "vit_set_workspace")
         self.workspace_bytes = nbytes
+
+    def set_option(self, name: str, value: int):
+        """Launch geometry of the calls made through THIS handle (vit_handle_set_option): 'reserve_cus'."""
+        check(self.lib.vit_handle_set_option(self.h, name.encode(), int(value)), f"vit_handle_set_option({name})")
 
     def ensure_workspace(self, nbytes: int):
         if nbytes > self.workspace_bytes:

@@ -13,6 +13,7 @@ struct vit_ctx {
   size_t ws_bytes;
   const void* step_state;  // device memory: vit::StepState, or NULL (vit_step_state_bind)
   int num_cus;             // compute units of the device (read once in vit_create): grid size of the persistent kernels
+  int reserve_cus;         // vit_handle_set_option("reserve_cus"): -1 = the process default (vit_set_option), else this handle's own
 };
 
 namespace vit {
@@ -41,7 +42,7 @@ int g_reserve_cus = 0;
 int ctx_num_cus(vit_handle h) {
   // without a handle (kernel-level calls of the C ABI that pass NULL): the current device, asked once
   static int dflt = 0;
-  if (h) return std::max(1, h->num_cus - g_reserve_cus);
+  if (h) return std::max(1, h->num_cus - (h->reserve_cus >= 0 ? h->reserve_cus : g_reserve_cus));
   if (!dflt) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -84,6 +85,7 @@ int vit_create(vit_handle* out, int device) {
   c->ws_bytes = 0;
   c->step_state = nullptr;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->reserve_cus = -1;
   *out = c;
   return VIT_OK;
 }
@@ -163,6 +165,17 @@ int vit_set_option(const char* name, int value) {
     return VIT_OK;
   }
   vit::set_error("vit_set_option: unknown option '%s'", name);
+  return VIT_ERR_ARG;
+}
+
+int vit_handle_set_option(vit_handle h, const char* name, int value) {
+  VIT_CHECK(h && name, VIT_ERR_ARG, "vit_handle_set_option: null handle or name");
+  if (strcmp(name, "reserve_cus") == 0) {
+    VIT_CHECK(value >= -1 && value <= 128, VIT_ERR_ARG, "vit_handle_set_option: reserve_cus takes -1 (process default) or 0 .. 128");
+    h->reserve_cus = value;
+    return VIT_OK;
+  }
+  vit::set_error("vit_handle_set_option: '%s' is not a per-handle option (only launch geometry is: reserve_cus)", name);
   return VIT_ERR_ARG;
 }
 

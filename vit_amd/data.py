@@ -19,7 +19,7 @@ from typing import Iterator, Optional, Sequence, Tuple
 
 import torch
 
-__all__ = ["SpecDataset", "SpecLoader", "SpecDataModule"]
+__all__ = ["SpecDataset", "SpecLoader", "SpecDataModule"]  # _Stager, _step_reads: the input path behind SpecLoader
 
 
 class SpecDataset:
@@ -107,29 +107,215 @@ class SpecDataset:
         return cls(flux, error, cols[0] if len(cols) == 1 else torch.stack(cols, dim=1), **kw)
 
 
+def _step_reads(ds: "SpecDataset") -> Tuple[bool, ...]:
+    """Which items of a batch tuple the step functions read (vit_amd/module.py; reference src/vit.py:83-92, 94-110):
+    training (flux, error, labels): `error` only feeds the noise injection, dead when noise_level == 0 (SURVEY 8a16);
+    evaluation 4-tuples (noisy, flux, error, labels): `noisy` or `flux`, never `error`; 3-tuples: flux.  Items the
+    step never reads are NOT moved to the device (their slot in the tuple is None): at ViT-B/16 224^2 the training split's
+    `error` is half of the 103 MB the reference's loader ships per step."""
+    if ds.noisy is not None:
+        return (True, True, False, True)  # the module picks noisy or clean by ITS noise level (module.py: _eval_inputs)
+    train = ds.stage in (None, "fit", "train")
+    return (True, bool(train and ds.noise_level > 0), True)
+
+
+class _Stager:
+    """Host-resident split -> device batches, `depth` batches ahead of the step (the reference: DataLoader(pin_memory,
+    persistent_workers), src/basemodule.py:76-85).  A worker thread gathers the rows of batch k + depth into a PINNED
+    staging buffer (torch releases the GIL inside index_select) and enqueues their H2D copy on a copy stream of its own;
+    the consumer only makes its stream wait for that copy's event.  `depth + 1` slots of (pinned, device) buffers; a
+    slot is refilled only after the step that read it has been enqueued (event recorded when the consumer lets go of it),
+    so a batch stays valid until the next-but-`depth` one is asked for."""
+
+    def __init__(self, cols, batches, device, depth: int = 2):
+        import queue
+        import threading
+
+        self.cols, self.batches, self.device = cols, batches, device
+        self.nslots = depth + 1
+        rows = max((len(j) for j in batches), default=0)
+        self.pinned = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, pin_memory=True)
+                        for c in cols] for _ in range(self.nslots)]
+        self.dev = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, device=device)
+                     for c in cols] for _ in range(self.nslots)]
+        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]
+        self.freed = [None] * self.nslots
+        self.stream = torch.cuda.Stream(device=device)
+        self.free_q: "queue.Queue" = queue.Queue()
+        self.ready_q: "queue.Queue" = queue.Queue()
+        for sl in range(self.nslots):
+            self.free_q.put(sl)
+        self.held = None
+        self.stop = False
+        self.error = None
+        self.thread = threading.Thread(target=self._work, name="vit_amd-stager", daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for j in self.batches:
+                sl = self.free_q.get()
+                if sl is None or self.stop:
+                    return
+                n = len(j)
+                self.ready[sl].synchronize()  # the slot's previous copy has left its pinned buffer (long since)
+                for c, pin in zip(self.cols, self.pinned[sl]):
+                    if c is not None:
+                        torch.index_select(c, 0, j, out=pin[:n])
+                with torch.cuda.stream(self.stream):
+                    if self.freed[sl] is not None:
+                        self.stream.wait_event(self.freed[sl])  # the step that read this slot's device buffers
+                    for pin, dv in zip(self.pinned[sl], self.dev[sl]):
+                        if pin is not None:
+                            dv[:n].copy_(pin[:n], non_blocking=True)
+                    self.ready[sl].record(self.stream)
+                self.ready_q.put((sl, n))
+            self.ready_q.put(None)
+        except BaseException as e:  # noqa: BLE001 - surfaced by the consumer
+            self.error = e
+            self.ready_q.put(None)
+
+    def _release(self):
+        if self.held is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.freed[self.held] = ev
+            self.free_q.put(self.held)
+            self.held = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self._release()
+        item = self.ready_q.get()
+        if item is None:
+            self.close()
+            if self.error is not None:
+                raise self.error
+            raise StopIteration
+        sl, n = item
+        torch.cuda.current_stream(self.device).wait_event(self.ready[sl])
+        self.held = sl
+        return tuple(None if dv is None else dv[:n] for dv in self.dev[sl])
+
+    def close(self):
+        self.stop = True
+        self.free_q.put(None)
+        if self.thread.is_alive() and self.thread is not __import__("threading").current_thread():
+            self.thread.join(timeout=5.0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class SpecLoader:
     """Batches with the reference's DataLoader semantics that matter to the step (basemodule.py:76-85): shuffle on the
-    training split unless debugging, DistributedSampler-style sharding over ranks, whole-tensor indexing (no workers)."""
+    training split unless debugging, DistributedSampler-style sharding over ranks.  The reference ships `2 * B * L * 4`
+    bytes per step from pageable host memory through pinned staging (`pin_memory`, workers); here, once a device is bound
+    (`bind(device)`, done by `Trainer.fit / validate`), the batch is produced ON the MI355X:
 
-    def __init__(self, ds: SpecDataset, batch_size: int, shuffle: bool = False, seed: int = 42, drop_last: bool = False):
+      placement 'device' -- the tensors the step reads are uploaded ONCE and a batch is a row gather in HBM (an index
+                            vector per epoch is all that crosses PCIe): 288 GB of HBM hold 1.4 M spectra of L = 50176.
+      placement 'host'   -- the split stays in host memory; a worker thread stages batches through pinned buffers and a
+                            copy stream, `prefetch` batches ahead of the step (`_Stager`).
+      placement 'auto'   -- 'device' when the needed tensors fit a quarter of the HBM that is free, else 'host'.
+
+    Without a bound device (CPU tests, tools) it yields host tensors by whole-tensor indexing as before.  Tuple items the
+    step never reads (`_step_reads`) are None on the device paths."""
+
+    def __init__(self, ds: SpecDataset, batch_size: int, shuffle: bool = False, seed: int = 42, drop_last: bool = False,
+                 placement: str = "auto", prefetch: int = 2, ship_error: Optional[bool] = None):
+        """`ship_error`: None = only when the dataset's noise level says the training step reads it; True = always (a module
+        whose noise level is set apart from the dataset's)."""
         self.ds, self.bs, self.shuffle, self.seed, self.epoch, self.drop_last = ds, batch_size, shuffle, seed, 0, drop_last
+        self.ship_error = ship_error
+        if placement not in ("auto", "device", "host"):
+            raise ValueError(f"placement must be 'auto', 'device' or 'host', got '{placement}'")
+        self.placement, self.prefetch = placement, max(1, int(prefetch))
+        self.device: Optional[torch.device] = None
+        self._resident = None  # device copies of the columns the step reads
+        self.resolved: Optional[str] = None
 
     def set_epoch(self, e: int) -> None:
         self.epoch = e
 
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, ...]]:
+    def __len__(self) -> int:
+        n = len(self._indices())
+        return n // self.bs if self.drop_last else -(-n // self.bs)
+
+    def bind(self, device) -> "SpecLoader":
+        """Produce batches on `device` from now on (no-op for a CPU device)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            return self
+        if self.device != device:
+            self.device, self._resident, self.resolved = device, None, None
+        return self
+
+    def _columns(self):
+        ds = self.ds
+        cols = (ds.noisy, ds.flux, ds.error, ds.labels) if ds.noisy is not None else (ds.flux, ds.error, ds.labels)
+        reads = list(_step_reads(ds))
+        if self.ship_error is not None:
+            reads[-2] = bool(self.ship_error)
+        return tuple(c if need else None for c, need in zip(cols, reads))
+
+    def _indices(self) -> torch.Tensor:
         import torch.distributed as dist
 
         from .ddp import shard_indices
 
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
-        idx = shard_indices(len(self.ds), rank, world, self.epoch, self.shuffle, self.seed)
+        return shard_indices(len(self.ds), rank, world, self.epoch, self.shuffle, self.seed)
+
+    def _batches(self):
+        idx = self._indices()
+        out = []
         for i in range(0, len(idx), self.bs):
             j = idx[i:i + self.bs]
             if self.drop_last and len(j) < self.bs:
                 break
-            yield self.ds[j]
+            out.append(j)
+        return out
+
+    def _resolve(self, cols) -> str:
+        if self.resolved is None:
+            mode = self.placement
+            if mode == "auto":
+                need = sum(c.numel() * c.element_size() for c in cols if c is not None)
+                free, _total = torch.cuda.mem_get_info(self.device)
+                mode = "device" if need <= free // 4 else "host"
+            self.resolved = mode
+        return self.resolved
+
+    def __iter__(self) -> Iterator[Tuple[Optional[torch.Tensor], ...]]:
+        if self.device is None:
+            for j in self._batches():
+                yield self.ds[j]
+            return
+        cols = self._columns()
+        if self._resolve(cols) == "device":
+            if self._resident is None:
+                self._resident = tuple(None if c is None else c.to(self.device) for c in cols)
+            batches = self._batches()
+            order = torch.cat(batches).to(self.device) if batches else None
+            pos = 0
+            for j in batches:
+                jd = order[pos:pos + len(j)]
+                pos += len(j)
+                yield tuple(None if c is None else c.index_select(0, jd) for c in self._resident)
+            return
+        st = _Stager(cols, self._batches(), self.device, depth=self.prefetch)
+        try:
+            yield from st
+        finally:
+            st.close()
 
 
 class SpecDataModule:
@@ -169,6 +355,7 @@ class SpecDataModule:
         self.noise_level = float((config.get("noise", {}) or {}).get("noise_level", 0.0) or 0.0)
         self.batch_size = int(train.get("batch_size", 64))
         self.debug = bool(train.get("debug", False))
+        self.placement = str(data.get("placement", "auto"))  # 'auto' | 'device' | 'host' (SpecLoader)
         self.train = self.val = self.test = None
 
     @classmethod
@@ -209,13 +396,13 @@ class SpecDataModule:
         return self
 
     def train_dataloader(self) -> "SpecLoader":
-        return SpecLoader(self.train, self.batch_size, shuffle=not self.debug)
+        return SpecLoader(self.train, self.batch_size, shuffle=not self.debug, placement=self.placement)
 
     def val_dataloader(self):
         if self.val is None or len(self.val) == 0:
             print("[WARNING] Validation dataset is None or empty - validation will be skipped")  # basemodule.py:88-94
             return None
-        return SpecLoader(self.val, min(max(self.batch_size, 1), len(self.val)))
+        return SpecLoader(self.val, min(max(self.batch_size, 1), len(self.val)), placement=self.placement)
 
     def test_dataloader(self) -> "SpecLoader":
-        return SpecLoader(self.test, self.batch_size)
+        return SpecLoader(self.test, self.batch_size, placement=self.placement)

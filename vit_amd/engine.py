@@ -162,6 +162,8 @@ class ViTEngine:
         # weight-gradient GEMMs on a second HIP stream (see _dw): None = off
         self.side_stream: Optional[torch.cuda.Stream] = None
         self._side_handle = None
+        self._main_handle = None  # this engine's own vit_handle (workspace + launch geometry): see handle()
+        self.reserve_cus = -1     # -1 = the process-wide vit_set_option value
         self._side_reads: Dict[str, object] = {}
         self.overlap_dw = True
         self._gen = 0  # bumped by every forward: the activation arena holds ONE forward, backward checks it is still that one
@@ -231,6 +233,26 @@ class ViTEngine:
         if self._shadow_version != ver:
             vf.cast_f32_bf16(self.flat, self.shadow)
             self._shadow_version = ver
+
+    def handle(self):
+        """This engine's own vit_handle.  Launch geometry (`reserve_cus`) and the split-K / reduction workspace belong to the
+        handle, so two engines of one process -- a training and an evaluation model, a sweep's trials -- do not see each
+        other's settings (include/vit_amd.h: vit_handle_set_option)."""
+        from . import _cabi
+
+        dev = self.flat.device
+        if self._main_handle is None or self._main_handle.device_index != (dev.index if dev.index is not None else torch.cuda.current_device()):
+            self._main_handle = _cabi.Handle(dev.index if dev.index is not None else torch.cuda.current_device())
+            self._main_handle.set_option("reserve_cus", self.reserve_cus)
+        return self._main_handle
+
+    def set_reserve_cus(self, n: int):
+        """CUs the one-workgroup-per-CU kernels of THIS engine leave to a collective that overlaps them (data-parallel runs);
+        -1 = follow the process-wide default."""
+        self.reserve_cus = int(n)
+        for h in (self._main_handle, self._side_handle):
+            if h is not None:
+                h.set_option("reserve_cus", self.reserve_cus)
 
     def mark_shadow_fresh(self):
         self._shadow_version = self.version_fn()
@@ -342,8 +364,12 @@ class ViTEngine:
 
     def forward(self, x: torch.Tensor, labels: Optional[torch.Tensor], training: bool, need_grad: bool,
                 output_hidden_states: bool = False, output_attentions: bool = False, capture_ctx: Optional[list] = None):
-        c = self.cfg
         self._ensure_device_state()
+        with vf.use_handle(self.handle()):
+            return self._forward(x, labels, training, need_grad, output_hidden_states, output_attentions, capture_ctx)
+
+    def _forward(self, x, labels, training, need_grad, output_hidden_states, output_attentions, capture_ctx):
+        c = self.cfg
         if x.dim() != 2 or x.shape[1] != c.image_size:
             raise ValueError(f"pixel_values must be [batch, {c.image_size}], got {tuple(x.shape)}")
         if not x.is_cuda:
@@ -433,8 +459,9 @@ class ViTEngine:
         st, c = self._last, self.cfg
         if st is None or not st["grad"] or st["gen"] != self._gen:
             raise VitError("saved_attentions(): the last forward did not keep per-layer activations")
-        return [vf.attention_probs(self.act["qkv"][i], st["B"], c.num_attention_heads, c.seq_len, c.head_dim,
-                                   c.head_dim ** -0.5) for i in range(c.num_hidden_layers)]
+        with vf.use_handle(self.handle()):
+            return [vf.attention_probs(self.act["qkv"][i], st["B"], c.num_attention_heads, c.seq_len, c.head_dim,
+                                       c.head_dim ** -0.5) for i in range(c.num_hidden_layers)]
 
     def _ln(self, x, name, out, mean, rstd):
         vf.layernorm_fwd(x, self.p(name + ".weight"), self.p(name + ".bias"), self.cfg.layer_norm_eps, out=out,
@@ -503,11 +530,16 @@ class ViTEngine:
             if self._side_handle is None:
                 self._side_handle = _cabi.Handle(self.flat.device.index if self.flat.device.index is not None
                                                  else torch.cuda.current_device())
+                self._side_handle.set_option("reserve_cus", self.reserve_cus)
         elif not on:
             self.side_stream = None
 
     # ------------------------------------------------------------------ backward
     def backward(self, dloss: torch.Tensor, need_dx: bool = False, gen: Optional[int] = None):
+        with vf.use_handle(self.handle()):
+            return self._backward(dloss, need_dx, gen)
+
+    def _backward(self, dloss: torch.Tensor, need_dx: bool = False, gen: Optional[int] = None):
         """Fill self.grads (every trainable slice exactly once) for the last forward; calls grad_ready_cb(lo, hi) as
         each bucket of the flat gradient buffer is complete (used to overlap the RCCL all-reduce).  `gen`: the forward this
         backward belongs to (ViTEngine._gen at that time); the arena holds one forward's activations, so a later forward

@@ -46,7 +46,8 @@ class GraphedTrainStep:
         flux, _, labels = batch
         self.module, self.opt, self.eng = module, optimizer, eng
         dev = eng.flat.device
-        self.h = _cabi.handle_for(dev)
+        eng._ensure_device_state()
+        self.h = eng.handle()  # the engine's own handle: its calls read the bound per-step record
         # per-step device record: [key0, key1 (u32) | lr, bc1, rsqrt_bc2 (f32) | step (u32) | pad]
         self.state = torch.zeros(8, dtype=torch.int32, device=dev)
         self._lr = None
@@ -108,7 +109,11 @@ class GraphedTrainStep:
 
     def _body(self):
         """The captured sequence.  Host-side scalars below (seed, step) are frozen at capture; their per-step versions
-        come from the bound device record."""
+        come from the bound device record.  Every call goes through the engine's handle (one workspace, held below)."""
+        with vf.use_handle(self.h):
+            return self._body_calls()
+
+    def _body_calls(self):
         eng, opt = self.eng, self.opt
         lib, h = self.h.lib, self.h.h
         st = torch.cuda.current_stream(eng.flat.device).cuda_stream

@@ -130,6 +130,9 @@ class ViTLModule(BaseLightningModule):
             return flux
         from . import functional as vf
 
+        if error is None:
+            raise ValueError("noise.noise_level > 0 needs the batch's `error` tensor; the loader left it on the host because the "
+                             "dataset was built with noise_level 0 (SpecLoader(ship_error=True) ships it regardless)")
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         return vf.add_noise(flux.contiguous().float(), error.contiguous().float(), float(self.noise_level), seed)
 

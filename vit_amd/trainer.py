@@ -61,7 +61,15 @@ def seed_everything(seed: int = 42):
 
 
 def _to_device(batch, device):
+    """Batches of a bound SpecLoader are already on the device (no-op); anything else (a plain iterable of host tensors) is
+    copied here -- from pageable memory that copy is synchronous, which is why the loaders stage through pinned buffers."""
     return tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
+
+
+def _bind(loader, device):
+    if loader is not None and hasattr(loader, "bind"):
+        loader.bind(device)
+    return loader
 
 
 def _batch_size(batch) -> int:
@@ -260,22 +268,80 @@ class Trainer:
         self._ready_for = module
 
     # ------------------------------------------------------------------ room for the collective
-    def autotune_reserve_cus(self, module, batch, candidates=(0, 8, 16, 32), steps=3):
-        """Data-parallel runs only: pick how many CUs the one-workgroup-per-CU kernels (ping-pong GEMMs, pair-pipelined attention
-        backward) leave free for the collective's kernels that overlap the backward (`vit_set_option("reserve_cus")`), by timing
-        `steps` optimisation steps on `batch` at each candidate (median of per-step hipEvent times, MAX over ranks) and keeping
-        the fastest; every rank takes the same decision.  The steps are real optimisation steps: call it during warm-up
-        (bench.py does; `fit` only with `train.ddp_reserve_cus: auto`, on its first batch).  Returns {candidate: ms}.
-        Reference: Lightning's 'ddp' strategy overlaps NCCL with backward on a GPU whose kernels do not own whole SMs; a
-        persistent grid that owns every CU must make that room itself."""
-        from . import _cabi
+    def _snapshot(self, module):
+        """Everything a training_step changes: parameters (the engine's flat buffer + a trainable preprocessor's), optimizer
+        state and step count, scheduler, global_step, the dropout stream's position, the epoch's running log sums and
+        torch's CPU generator (the noise injection draws its per-step seed from it)."""
+        import copy
 
+        eng, opt = module.model.engine, self.optimizer
+        eng._ensure_device_state()
+        snap = {"flat": eng.flat.detach().clone(), "step_counter": eng.step_counter, "global_step": self.global_step,
+                "acc": {k: [None if v[0] is None else v[0].clone(), v[1]] for k, v in self._acc.items()},
+                "rng": torch.random.get_rng_state(),
+                "sched": copy.deepcopy(self.sched_cfg["scheduler"].state_dict()) if self.sched_cfg else None,
+                "lr": [g["lr"] for g in opt.param_groups]}
+        if isinstance(opt, FusedAdamW):
+            snap["fused"] = (opt._step, None if opt._m is None else opt._m.clone(), None if opt._v is None else opt._v.clone(),
+                             {k: (a.clone(), b.clone()) for k, (a, b) in opt._extra_state.items()},
+                             [p.detach().clone() for p in opt._extras])
+        else:
+            snap["opt"] = copy.deepcopy(opt.state_dict())
+            snap["extra_params"] = [p.detach().clone() for p in module.parameters()]
+        return snap
+
+    def _restore(self, module, snap):
+        eng, opt = module.model.engine, self.optimizer
+        torch.cuda.synchronize(self.device)
+        with torch.no_grad():
+            eng.flat.copy_(snap["flat"])
+        eng._shadow_version = -1  # the bf16 shadow is re-cast from the restored master weights
+        eng.step_counter, self.global_step = snap["step_counter"], snap["global_step"]
+        self._acc = snap["acc"]
+        torch.random.set_rng_state(snap["rng"])
+        if self.sched_cfg:
+            self.sched_cfg["scheduler"].load_state_dict(snap["sched"])
+        if "fused" in snap:
+            step, m, v, extra_state, extras = snap["fused"]
+            opt._step = step
+            if m is None:
+                opt._m = opt._v = None
+            else:
+                opt._m.copy_(m); opt._v.copy_(v)
+            opt._extra_state = extra_state
+            with torch.no_grad():
+                for p, q in zip(opt._extras, extras):
+                    p.copy_(q)
+        else:
+            opt.load_state_dict(snap["opt"])
+            with torch.no_grad():
+                for p, q in zip(module.parameters(), snap["extra_params"]):
+                    p.copy_(q)
+        for g, lr in zip(opt.param_groups, snap["lr"]):
+            g["lr"] = lr
+        opt.zero_grad(set_to_none=True)
+
+    def set_reserve_cus(self, module, n: int):
+        """Launch geometry of THIS module's engine (its own vit_handle): nothing process-wide changes."""
+        self.reserve_cus = int(n)
+        module.model.engine.set_reserve_cus(self.reserve_cus)
+
+    def autotune_reserve_cus(self, module, batch, candidates=(0, 8, 16, 32), steps=3, restore: bool = True):
+        """Data-parallel runs only: pick how many CUs the one-workgroup-per-CU kernels (ping-pong GEMMs, pair-pipelined attention
+        backward) leave free for the collective's kernels that overlap the backward (vit_handle_set_option "reserve_cus"), by
+        timing `steps` optimisation steps on `batch` at each candidate (median of per-step hipEvent times, MAX over ranks) and
+        keeping the fastest; every rank takes the same decision.  The timed steps are real optimisation steps, so the state
+        they change is snapshotted before and put back afterwards (`restore`; ADVICE r4: with lr 1e-3 and no warm-up ONE step
+        moves the C3 loss 0.185 -> 266, and the reference's DDP does nothing of the kind before epoch 0,
+        src/basemodule.py:226-251): a run with 'auto' continues bit for bit like a run with the chosen value fixed.  bench.py
+        calls it ahead of its warm-up with restore=False (those steps ARE warm-up).  Returns {candidate: ms}."""
         if not self.exchanging:
             return {}
         dist = torch.distributed
+        snap = self._snapshot(module) if restore else None
         out = {}
         for c in candidates:
-            _cabi.set_option("reserve_cus", int(c))
+            self.set_reserve_cus(module, int(c))
             self.training_step(module, batch, 0)  # the grids' first launch at this size
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
             torch.cuda.synchronize()
@@ -289,8 +355,9 @@ class Trainer:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             out[int(c)] = float(t.median())
         best = min(out, key=lambda k: (out[k], k))
-        _cabi.set_option("reserve_cus", best)
-        self.reserve_cus = best
+        self.set_reserve_cus(module, best)
+        if snap is not None:
+            self._restore(module, snap)
         return out
 
     # ------------------------------------------------------------------ one optimisation step
@@ -354,6 +421,7 @@ class Trainer:
         for m in metrics.values():
             m.reset()
         stage = "validation" if prefix == "val" else "test"
+        _bind(loader, self.device)
         hook = getattr(module, f"on_{stage}_start", None)
         if hook:
             hook()
@@ -432,7 +500,7 @@ class Trainer:
         torch left behind -- a 50-100 ms pause of the launching thread during which the GPU drains (measured in bench.py's
         per-step list: one 105 ms step among 35 ms ones).  With the start-up heap frozen, collections only scan what the steps
         themselves allocated.  Idempotent; the reference gets the same effect from nothing (its step is a handful of Python
-        calls into a C++ autograd engine)."""
+        calls into a C++ autograd engine).  `fit()` undoes it (gc.unfreeze()) when it returns."""
         import gc
 
         gc.collect()
@@ -441,49 +509,68 @@ class Trainer:
     def fit(self, module, train_loader: Iterable, val_loader: Optional[Iterable] = None, ckpt_path: Optional[str] = None):
         self._es_best, self._es_bad = None, 0
         self._setup(module)
+        _bind(train_loader, self.device)
         first_epoch = self._resume(module, ckpt_path) if ckpt_path else 0
+        peeked = None  # (first batch, the rest) of a ONE-SHOT iterable whose first batch the autotune looked at
         if self.exchanging and str(self.reserve_cus_cfg) not in ("0", "", "None"):
             if str(self.reserve_cus_cfg).lower() == "auto":
+                # times a few steps on the first batch and puts every piece of training state back (autotune_reserve_cus):
+                # the batch is only PEEKED -- a re-iterable loader starts again from its first batch, a one-shot iterator
+                # gets the batch chained back in front
                 module.train()
-                first = next(iter(train_loader), None)
+                it = iter(train_loader)
+                first = next(it, None)
+                if it is train_loader:
+                    peeked = (first, it)
                 if first is not None:
                     tuned = self.autotune_reserve_cus(module, _to_device(first, self.device))
                     if self.verbose:
                         print(f"[trainer] reserve_cus autotune (ms per step) {tuned} -> {self.reserve_cus}")
+                if hasattr(it, "close") and it is not train_loader:
+                    it.close()
             else:
-                from . import _cabi
+                self.set_reserve_cus(module, int(self.reserve_cus_cfg))
+        import gc
+        import itertools
 
-                self.reserve_cus = int(self.reserve_cus_cfg)
-                _cabi.set_option("reserve_cus", self.reserve_cus)
         self.freeze_heap()
-        epochs = 1 if self.fast_dev_run else self.max_epochs
-        for epoch in range(first_epoch, epochs):
-            self.current_epoch = module.current_epoch = epoch
-            if self.freeze.on_epoch_start(module.model, epoch) and self.verbose:
-                print(f"[trainer] epoch {epoch}: input preprocessor unfrozen")
-            if hasattr(train_loader, "set_epoch"):
-                train_loader.set_epoch(epoch)
-            module.train()
-            t0 = time.time()
-            for i, batch in enumerate(train_loader):
-                self.training_step(module, _to_device(batch, self.device), i)
-                if self.fast_dev_run:
+        try:
+            epochs = 1 if self.fast_dev_run else self.max_epochs
+            for epoch in range(first_epoch, epochs):
+                self.current_epoch = module.current_epoch = epoch
+                if self.freeze.on_epoch_start(module.model, epoch) and self.verbose:
+                    print(f"[trainer] epoch {epoch}: input preprocessor unfrozen")
+                if hasattr(train_loader, "set_epoch"):
+                    train_loader.set_epoch(epoch)
+                module.train()
+                t0 = time.time()
+                batches = train_loader
+                if peeked is not None:
+                    batches = itertools.chain([] if peeked[0] is None else [peeked[0]], peeked[1])
+                    peeked = None
+                for i, batch in enumerate(batches):
+                    self.training_step(module, _to_device(batch, self.device), i)
+                    if self.fast_dev_run:
+                        break
+                logs = self._flush_epoch_logs()
+                if val_loader is not None:
+                    logs.update(self.validate(module, val_loader, "val"))
+                self._step_epoch_scheduler(logs)
+                logs["lr"] = self.optimizer.param_groups[0]["lr"]
+                logs["epoch_time_s"] = time.time() - t0
+                self.history.append(logs)
+                self.logged.update(logs)
+                if self.verbose:
+                    print(f"[epoch {epoch}] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(logs.items())))
+                if self.checkpointer is not None and val_loader is not None:
+                    self.checkpointer.after_validation(self, module, logs)
+                if self._early_stop(logs):
+                    self.should_stop = True
                     break
-            logs = self._flush_epoch_logs()
-            if val_loader is not None:
-                logs.update(self.validate(module, val_loader, "val"))
-            self._step_epoch_scheduler(logs)
-            logs["lr"] = self.optimizer.param_groups[0]["lr"]
-            logs["epoch_time_s"] = time.time() - t0
-            self.history.append(logs)
-            self.logged.update(logs)
-            if self.verbose:
-                print(f"[epoch {epoch}] " + " ".join(f"{k}={v:.5g}" for k, v in sorted(logs.items())))
-            if self.checkpointer is not None and val_loader is not None:
-                self.checkpointer.after_validation(self, module, logs)
-            if self._early_stop(logs):
-                self.should_stop = True
-                break
+        finally:
+            # everything alive at freeze time (models, engines, optimizers of EARLIER fits in this process) sat in
+            # the permanent generation for good; hand it back so that cyclic garbage among them can be collected again
+            gc.unfreeze()
         return self.history
 
     def _step_epoch_scheduler(self, logs):
