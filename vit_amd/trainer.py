@@ -339,6 +339,8 @@ class Trainer:
             return {}
         dist = torch.distributed
         snap = self._snapshot(module) if restore else None
+        # a per-step scheduler (one-cycle) has a fixed number of steps to give: the probe steps do not take from it
+        sched_cfg, self.sched_cfg = self.sched_cfg, (None if restore else self.sched_cfg)
         out = {}
         for c in candidates:
             self.set_reserve_cus(module, int(c))
@@ -356,6 +358,7 @@ class Trainer:
             out[int(c)] = float(t.median())
         best = min(out, key=lambda k: (out[k], k))
         self.set_reserve_cus(module, best)
+        self.sched_cfg = sched_cfg
         if snap is not None:
             self._restore(module, snap)
         return out
