@@ -145,7 +145,11 @@ typedef struct vit_gemm_desc {
    * columns [0, rope_cols) of C are heads of rope_dh columns whose element i pairs with element i + rope_dh / 2, row m is token
    * m % rope_T; cos / sin: f32 [rope_T, rope_dh / 2] (vit_rope_qk's tables).  NULL = off.  The ping-pong core rotates in its
    * epilogue, on the f32 values before the one rounding to bf16 (rope_dh 16 / 32 / 64, rope_cols a multiple of 64); every
-   * other case runs vit_rope_qk on C right after the product -- same contract either way. */
+   * other case runs vit_rope_qk on C right after the product -- same contract either way, PROVIDED the tables are the
+   * reference's: row t holds the angles t * theta_i, linear in t and zero-based (rope.py:36-56).  The rotating epilogue reads
+   * eight table rows per tile and steps a lane's later rows by the angle-addition recurrence over table row 8, so a table of
+   * other positions (offset, scaled, learned) is NOT supported through this descriptor: rotate with vit_rope_qk, which reads
+   * the table per row.  dropout_p must be 0 with rope (the reference rotates before any dropout). */
   const float* rope_cos; const float* rope_sin;
   int rope_T, rope_dh, rope_cols;
 } vit_gemm_desc;

@@ -487,9 +487,10 @@ int gemm_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st) {
   if (d && d->rope_cos) {
     VIT_CHECK(d->rope_sin && d->rope_T > 0 && d->rope_dh >= 8 && (d->rope_dh % 8) == 0 && d->rope_cols > 0 &&
                   (d->rope_cols % (2 * d->rope_dh)) == 0 && d->rope_cols <= d->N && d->rows_per_batch == 0 && !d->colsum_out &&
-                  d->act == VIT_ACT_NONE && !d->residual && d->split_k <= 1,
-              VIT_ERR_ARG, "vit_gemm: rope needs sin, T > 0, head_dim %% 8 == 0, rope_cols = 2 x heads x head_dim <= N, and a plain "
-                           "(bias / dropout-free) projection without row map, column sums, residual or split-K");
+                  d->act == VIT_ACT_NONE && !d->residual && d->split_k <= 1 && d->dropout_p == 0.f,
+              VIT_ERR_ARG, "vit_gemm: rope needs sin, T > 0, head_dim %% 8 == 0, rope_cols = 2 x heads x head_dim <= N, and a "
+                           "projection (a bias is fine) without dropout, row map, column sums, residual or split-K: the pass "
+                           "behind a dropped-out product would rotate AFTER the dropout, which is not the reference's order");
   }
   int rc = gemm_launch_core(h, d, st);
   if (rc == VIT_OK && d->rope_cos && !g_rope_fused)  // the core had no rotating epilogue for this shape: the separate pass

@@ -1268,7 +1268,8 @@ int gemm2_try_launch(vit_handle h, const vit_gemm_desc* d, hipStream_t st, int* 
     // the bf16 fast epilogues store through 32-bit buffer offsets (raw buffer stores, sc1): outputs past 2 GiB keep the
     // generic epilogue (a clamped descriptor would drop the stores beyond it silently)
     if (((epi5 >= 3 && epi5 <= 6) || epi5 == 8) &&
-        ((unsigned long long)d->M * d->ldc * 2 >= 0x7FFFFFF0ull || (d->aux_out && (unsigned long long)d->M * d->ldaux * 2 >= 0x7FFFFFF0ull)))
+        ((unsigned long long)d->M * d->ldc * 2 >= 0x7FFFFFF0ull ||
+         ((d->aux_out || d->aux_in) && (unsigned long long)d->M * d->ldaux * 2 >= 0x7FFFFFF0ull)))  // aux_in: epilogue 5's loads
       epi5 = epi;
   }
   // the tiles of a partial last round go to the half-tile kernel (two workgroups per tile) when the epilogue is one of

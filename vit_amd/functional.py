@@ -69,7 +69,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, M: int, N: int, K: int, a_trans: b
          colsum_out: Optional[torch.Tensor] = None,
          rope: Optional[Tuple[torch.Tensor, torch.Tensor, int, int, int]] = None) -> torch.Tensor:
     """`rope = (cos, sin, T, head_dim, cols)`: rotary embedding of columns [0, cols) of the output (the q / k thirds of a fused QKV
-    projection; cos / sin: f32 [T, head_dim / 2]) -- in the GEMM's epilogue where the kernel can, by a vit_rope_qk pass behind it
+    projection; cos / sin: f32 [T, head_dim / 2], rows = the reference's LINEAR zero-based positions t * theta_i -- the rotating
+    epilogue steps angles by a recurrence over table row 8; other tables: `rope_qk`) -- in the GEMM's epilogue where the kernel can, by a vit_rope_qk pass behind it
     otherwise (the library decides; same result contract)."""
     h = _h(a)
     if a.dtype != b.dtype or a.dtype not in _DT:
