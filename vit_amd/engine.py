@@ -526,7 +526,9 @@ class ViTEngine:
 
         on = self.overlap_dw and self.precision == "bf16"
         if on and self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.flat.device)
+            import os
+
+            self.side_stream = torch.cuda.Stream(device=self.flat.device, priority=int(os.environ.get("VIT_SIDE_STREAM_PRIORITY", "0")))
             if self._side_handle is None:
                 self._side_handle = _cabi.Handle(self.flat.device.index if self.flat.device.index is not None
                                                  else torch.cuda.current_device())
