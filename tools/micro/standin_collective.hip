@@ -3,7 +3,12 @@
 // collective's footprint and none of its links: `wgs` persistent workgroups of 256 threads (RCCL channels), each streaming its
 // share of the gradient bucket through the CU (read + write in place, x * 1.0f: twice the bucket in HBM traffic, what a ring
 // step costs the local memory), PACED against the 100 MHz wall clock so that the bucket takes bytes * 2 (n - 1) / n / busbw
-// seconds -- the time xGMI would need -- however fast HBM could serve it.  Every workgroup reaches the end of its share
+// seconds -- the time xGMI would need -- however fast HBM could serve it.  FOOTPRINT = RCCL's own: the gfx950 code object of
+// this image's librccl.so (torch/lib, RCCL 2.26.6) holds rcclGenericKernel<1|2|4, *> with 256 threads per workgroup,
+// 19 744 bytes of LDS and 261-280 VGPRs (17-32 of them AGPRs) -- read from its .amdgpu_metadata notes -- so a channel cannot
+// share a CU with a ping-pong GEMM workgroup (160 KiB of LDS, 2 x 232 VGPRs per SIMD) or with the pair-pipelined attention
+// backward: the stand-in allocates the same LDS and clobbers v255 / a7 so that its descriptor asks for 264 registers.
+// Every workgroup reaches the end of its share
 // (bounded loop, bounded waits: at most `ticks_total` ticks past its start), so the grid always drains.
 // Build (tools/standin_sweep.py does it): hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libstandin.so standin_collective.hip
 #include <hip/hip_runtime.h>
@@ -12,6 +17,9 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __global__ __launch_bounds__(256) void standin_kernel(float* buf, long n4, long chunk4, unsigned long long ticks_per_chunk) {
+  __shared__ float lds[19744 / 4];
+  lds[threadIdx.x] = 0.f;                                  // the allocation is what matters: a resident channel's LDS
+  asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a7, 0" ::: "v255", "a7");  // 256 + 8 registers in the descriptor
   const unsigned long long t0 = wall_clock64();
   const long per = (n4 + gridDim.x - 1) / gridDim.x;
   const long lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
@@ -30,6 +38,7 @@ __global__ __launch_bounds__(256) void standin_kernel(float* buf, long n4, long 
     const unsigned long long deadline = t0 + (unsigned long long)done * ticks_per_chunk;
     while (wall_clock64() < deadline) __builtin_amdgcn_s_sleep(32);
   }
+  if (lds[threadIdx.x] != 0.f) buf[0] = 0.f;  // never true: keeps the LDS array alive
 }
 
 extern "C" int standin_launch(void* buf, long n_floats, int wgs, double seconds, void* stream) {
