@@ -337,13 +337,17 @@ def main():
     if args.launch_check:
         return launch_check(args.gpus)
 
+    # stdout carries ONE JSON line: libraries write there too (RCCL prints a version banner when its first communicator is
+    # created), so file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     from vit_amd import _cabi
     from vit_amd import ddp as ddp_mod
     from vit_amd import functional as vf
-    from vit_amd.module import ViTLModule
-    from vit_amd.trainer import Trainer, seed_everything
 
     rank, local, world = ddp_mod.init_distributed()
     # exchanging: N > 1, or VIT_DIST_SINGLE=1 (one rank, but the process group exists and every collective of the step runs:
@@ -640,7 +644,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary, "input_pipeline": input_pipeline,
             "comm": comm, "kernels": kernels,
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if exchanging:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
