@@ -376,3 +376,50 @@ def test_cli_checkpoint_resolution(tmp_path):
     assert resolve_checkpoint("best", str(d)).endswith("epoch=2-val_mae=0.1000.ckpt")
     assert resolve_checkpoint("last", str(d)) == str(d / "last.ckpt")
     assert resolve_checkpoint("/some/path.ckpt", str(d)) == "/some/path.ckpt"
+
+
+def test_loader_ships_only_what_the_step_reads():
+    """`error` is dead weight when noise_level = 0.  `_step_reads` decides which tuple items a bound loader moves to
+    the device; without a device (here) the loader yields the reference's full host tuples, in DistributedSampler order, with a
+    partial last batch, and `len()` counts batches."""
+    import torch
+
+    from vit_amd.data import SpecDataset, SpecLoader, _step_reads
+
+    g = torch.Generator().manual_seed(0)
+    mk = lambda stage, noise: SpecDataset(torch.rand((37, 16), generator=g), torch.rand((37, 16), generator=g),
+                                          torch.rand((37,), generator=g), task="reg", stage=stage, noise_level=noise)
+    assert _step_reads(mk("train", 0.0)) == (True, False, True)          # (flux, error, labels)
+    assert _step_reads(mk("train", 0.2)) == (True, True, True)           # the noise injection reads error (vit.py:86-88)
+    assert _step_reads(mk("val", 0.0)) == (True, False, True)
+    assert _step_reads(mk("val", 0.2)) == (True, True, False, True)      # (noisy, flux, error, labels): never error
+    ds = mk("train", 0.0)
+    ld = SpecLoader(ds, 8, shuffle=True, seed=3)
+    batches = list(ld)
+    assert len(batches) == len(ld) == 5 and [len(b[0]) for b in batches] == [8, 8, 8, 8, 5]
+    assert all(len(b) == 3 and b[1] is not None for b in batches)       # host iteration: the full tuple
+    seen = torch.cat([b[2] for b in batches])
+    assert torch.equal(seen.sort().values, ds.labels.sort().values)
+    assert len(SpecLoader(ds, 8, drop_last=True)) == 4
+    with pytest.raises(ValueError, match="placement"):
+        SpecLoader(ds, 8, placement="gpu")
+    assert SpecLoader(ds, 8).bind("cpu").device is None                   # a CPU device binds nothing
+
+
+def test_engine_refuses_unsupported_shapes_at_construction():
+    """what no kernel takes is a ValueError when the model is built, not a VIT_ERR_UNSUPPORTED in the middle of a
+    step.  head_dim 4 (hidden 32 / 8 heads, configs/sweep.yaml:13-18) is supported; head_dim 6 / 132, hidden % heads are not."""
+    from vit_amd.config import ViTConfig
+    from vit_amd.engine import ViTEngine
+
+    ok = dict(task_type="reg", image_size=4096, patch_size=8, num_hidden_layers=1, stride_size=1, num_labels=1)
+    eng = ViTEngine(ViTConfig(hidden_size=32, num_attention_heads=8, **ok))
+    assert eng.cfg.head_dim == 4 and eng.cfg.seq_len == 4090
+    for hidden, heads in ((48, 8), (264, 2), (40, 3)):
+        with pytest.raises(ValueError):
+            ViTEngine(ViTConfig(hidden_size=hidden, num_attention_heads=heads, **ok))
+    big = ViTEngine(ViTConfig(hidden_size=32, num_attention_heads=2, task_type="reg", image_size=8192, patch_size=8,
+                              num_hidden_layers=1, stride_size=1, num_labels=1))
+    with pytest.raises(ValueError, match="4096"):
+        big.set_precision("32")          # fp32 attention keeps a score row in the LDS: at most 4096 tokens
+    assert big.set_precision("bf16-mixed") == "bf16"
