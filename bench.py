@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-GEMM HIP-event brackets")
     ap.add_argument("--no-overlap", action="store_true", help="weight-gradient GEMMs on the main stream (no second HIP stream)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="weight-gradient GEMMs on a second HIP stream whatever the shape (default: the engine decides from the tile "
+                         "count -- one stream at the benchmarked B = 256, two where the GEMM grids leave >= 30 %% of the CUs idle)")
     ap.add_argument("--graph", action="store_true",
                     help="N = 1: replay the step as one captured hipGraph (vit_amd/graph.py) instead of launching its kernels. "
                          "Measured equal to eager launches within noise (the host runs ahead of the GPU either way) and 0.7 ms "
@@ -376,6 +379,8 @@ def main():
         trainer.set_reserve_cus(module, args.reserve_cus)
     if args.no_overlap or use_graph:
         module.model.engine.overlap_dw = False
+    elif args.overlap:
+        module.model.engine.overlap_dw = True
     lib = _cabi.load()
 
     def barrier():
@@ -467,11 +472,12 @@ def main():
     dt = time.perf_counter() - t0
     gc.callbacks.remove(gc_cb)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    two_streams = module.model.engine.side_stream is not None  # what the timed steps ran with (engine: overlap_dw "auto")
     # The per-GEMM HIP-event brackets (two event records around each of ~170 vit_gemm calls per step) are installed ONLY for
     # this repetition of the same steps (same state, same inputs): the clean region above ran the library's own vf.gemm, so
     # `value` carries no event record beyond the K + 1 step marks.  `roofline.instrumented_ms_per_step` is what the bracketed
-    # steps took -- on ONE stream (each GEMM alone on the GPU: with the weight-gradient GEMMs on their second stream a bracket
-    # would time two kernels sharing the CUs), so its distance to `ms_per_step` = event cost - what the second stream buys.
+    # steps took -- on ONE stream (each GEMM alone on the GPU: with the weight-gradient GEMMs on a second stream a bracket
+    # would time two kernels sharing the CUs); `event_cost_ms_per_step` = bracketed - the same one-stream steps without brackets.
     records = []
     dt_inst, n_inst = None, 0
     if not args.no_kernel_timing:
@@ -639,7 +645,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "train_gflop_per_image": round(flop_img / 1e9, 2),
                        "final_loss": final_loss, "reserve_cus": args.reserve_cus,
                        "launch": "one hipGraph replay per step" if use_graph else
-                       ("eager launches, weight-gradient GEMMs on a second HIP stream" if module.model.engine.overlap_dw
+                       ("eager launches, weight-gradient GEMMs on a second HIP stream" if two_streams
                         else "eager launches, one stream")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary, "input_pipeline": input_pipeline,
             "comm": comm, "kernels": kernels,

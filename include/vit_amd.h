@@ -64,9 +64,10 @@ int vit_set_workspace(vit_handle h, void* ws, size_t bytes);
  *   "gemm_ngroups": 1 (default) = XCDs 0-3 / 4-7 walk the lower / upper half of the N-tiles when the weights exceed an L2.
  *   "attn_res_max_t": longest sequence the resident attention kernels take (default 592 = what fits the LDS at head_dim
  *                64); longer ones, or everything with 0, go to the tiled kernels.
- *   "gemm_half_tail": 1 (default) = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
+ *   "gemm_half_tail": 1 = the tiles of a partial last round of a multi-round ping-pong GEMM (bias/dropout -> bf16
  *                and plain dX epilogues; 2 = the GELU epilogue too) run in a second launch as half tiles, two workgroups per
- *                tile; 0 = one launch.
+ *                tile; 0 (default since r05) = one launch: the half tiles shorten that product but cost more CU-time, and
+ *                inside the power-limited training step the single launch is faster overall.  Same results bit for bit.
  *   "reserve_cus": 0 (default) .. 128 = the one-workgroup-per-CU kernels (ping-pong GEMMs, pair-pipelined attention backward) size
  *                their grids for that many fewer CUs, leaving room for a collective's kernels that overlap them (data-parallel
  *                runs; bench.py --reserve-cus).

@@ -29,7 +29,7 @@ def main():
         _cabi.set_option("gemm_core", int(core))
         _cabi.set_option("gemm_pp_slots", 8)  # the 10-slot ring is gone
         _cabi.set_option("gemm_balance_wgs", int(bal) if bal else 1)
-        _cabi.set_option("gemm_half_tail", int(half) if half else 1)
+        _cabi.set_option("gemm_half_tail", int(half) if half else 0)
     dev = torch.device("cuda:0")
     M, D, F = args.M, 768, 3072
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -78,7 +78,7 @@ def main():
     _cabi.set_option("gemm_core", 1)
     _cabi.set_option("gemm_pp_slots", 8)
     _cabi.set_option("gemm_balance_wgs", 1)
-    _cabi.set_option("gemm_half_tail", 1)
+    _cabi.set_option("gemm_half_tail", 0)
     tot = {c: 0.0 for c in cores}
     print(f"{'case':48s} " + " ".join(f"core{c}: us / TF".rjust(20) for c in cores))
     for name, (fn, fl) in cases.items():

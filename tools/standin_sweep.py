@@ -88,8 +88,7 @@ def main():
     lib = build_standin()
     module, trainer, batch, _ = bench.build_run("vit_b16_224", 256, "bf16-mixed", dev, 0)
     eng = module.model.engine
-    if a.no_overlap:
-        eng.overlap_dw = False
+    eng.overlap_dw = not a.no_overlap
     rep = itertools.repeat(batch)
 
     def run(standin, reserve):

@@ -1116,7 +1116,12 @@ static int launch_tail_reduce(const Gemm2Args& a, int epi, hipStream_t st) {
 
 int g_split_tail = 1;  // vit_set_option("gemm_split_tail"): K-slices instead of half tiles for a short tail of a long-K GEMM
 int g_grp2 = 1;  // vit_set_option("gemm_ngroups"): 1 = two N-groups for weights larger than an L2 (see tile_coords)
-int g_half_tail = 1;  // vit_set_option("gemm_half_tail")
+// vit_set_option("gemm_half_tail").  Default 0 since r05: the second launch shortens the N = 768 products themselves (-5...9 % in
+// the micro-benchmark) but spends 5 % more CU-time (a half tile costs 0.7 of a tile), and the step is power-limited: with it off,
+// one launch of ceil(tiles / rounds) workgroups leaves 59 CUs idle for the kernel and every OTHER kernel of the step runs 1-3 %
+// faster (FC1 299 -> 292 us, attention backward 288 -> 281, dW 145.3 -> 143.3; step -0.4 ms at ViT-B on three boxes, ViT-L with
+// its second stream 53.6 -> 51.7 ms)
+int g_half_tail = 0;
 int g_balance_wgs = 1;  // vit_set_option("gemm_balance_wgs")
 int g_pp_slots = 8;  // vit_set_option("gemm_pp_slots"): half-tile slots of the ping-pong ring, 8 (default) or 10
 template <int AT, int BT, int EPI, int NSLOT>

@@ -165,7 +165,9 @@ class ViTEngine:
         self._main_handle = None  # this engine's own vit_handle (workspace + launch geometry): see handle()
         self.reserve_cus = -1     # -1 = the process-wide vit_set_option value
         self._side_reads: Dict[str, object] = {}
-        self.overlap_dw = True
+        # True / False / "auto": the second stream pays when the main stream's GEMMs leave a large part of the chip idle for
+        # whole kernels (see _want_side)
+        self.overlap_dw = "auto"
         self._gen = 0  # bumped by every forward: the activation arena holds ONE forward, backward checks it is still that one
         self.grad_ready_cb: Optional[Callable[[int, int], None]] = None
         # Parameters are views of `flat` with their OWN version counters (nn.Parameter / .data re-pointing do not share
@@ -521,10 +523,28 @@ class ViTEngine:
         with torch.cuda.stream(self.side_stream):
             cb(lo, hi)
 
+    def _want_side(self) -> bool:
+        """`overlap_dw == "auto"`: second stream iff the balanced grid of this batch's [M, D] x [D, D] products leaves at least
+        30 % of the CUs without a workgroup (the dW GEMMs then run on CUs nobody uses).  Measured on MI355X with the half-tile
+        tail launch off (r05, tools/stream_rule.sh; the chip is power-limited, so CU-time spent is what counts): ViT-B at B = 64 /
+        128 (41 % idle) two streams +3.5 %, ViT-L at B = 32 (43 %) +3.7 %; ViT-B at B = 192 ... 512 (7-23 % idle) within +-0.6 %,
+        and at the benchmarked B = 256 one stream wins by 0.5-1 % -- there the hand-off gaps between the streams (0.6 ms per
+        step, profiles/r05_a_gaps.txt) cost more than the overlap returns.  Shapes off the 256-aligned core: two streams."""
+        if self.overlap_dw != "auto":
+            return bool(self.overlap_dw)
+        D = self.cfg.hidden_size
+        Mp = getattr(self, "_Mp", 0)
+        if D % 256 or not Mp or Mp % 256:
+            return True
+        cus = max(1, torch.cuda.get_device_properties(self.flat.device).multi_processor_count - max(0, self.reserve_cus))
+        tiles = (Mp // 256) * (D // 256)
+        rounds = -(-tiles // cus)
+        return -(-tiles // rounds) <= 0.7 * cus
+
     def _setup_side(self):
         from . import _cabi
 
-        on = self.overlap_dw and self.precision == "bf16"
+        on = self.precision == "bf16" and self._want_side()
         if on and self.side_stream is None:
             import os
 
