@@ -127,19 +127,20 @@ class _Stager:
     slot is refilled only after the step that read it has been enqueued (event recorded when the consumer lets go of it),
     so a batch stays valid until the next-but-`depth` one is asked for."""
 
-    def __init__(self, cols, batches, device, depth: int = 2):
+    def __init__(self, cols, batches, device, depth: int = 2, buffers=None, carry=None):
         import queue
         import threading
 
         self.cols, self.batches, self.device = cols, batches, device
         self.nslots = depth + 1
         rows = max((len(j) for j in batches), default=0)
-        self.pinned = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, pin_memory=True)
-                        for c in cols] for _ in range(self.nslots)]
-        self.dev = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, device=device)
-                     for c in cols] for _ in range(self.nslots)]
-        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]
-        self.freed = [None] * self.nslots
+        if buffers is None:
+            buffers = self.make_buffers(cols, rows, device, self.nslots)
+        self.pinned, self.dev = buffers
+        # `carry` = (ready, freed) events of the stager that used these buffers in the previous epoch: its last copies out of
+        # the pinned buffers and the last steps that read the device buffers order this epoch's first refills
+        self.ready, self.freed = carry if carry is not None else ([torch.cuda.Event() for _ in range(self.nslots)],
+                                                                  [None] * self.nslots)
         self.stream = torch.cuda.Stream(device=device)
         self.free_q: "queue.Queue" = queue.Queue()
         self.ready_q: "queue.Queue" = queue.Queue()
@@ -150,6 +151,16 @@ class _Stager:
         self.error = None
         self.thread = threading.Thread(target=self._work, name="vit_amd-stager", daemon=True)
         self.thread.start()
+
+    @staticmethod
+    def make_buffers(cols, rows, device, nslots):
+        """(pinned, device) staging buffers, one set per slot; the loader keeps them across epochs (page-locking 3 x 51 MB
+        is tens of milliseconds)."""
+        pinned = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, pin_memory=True)
+                   for c in cols] for _ in range(nslots)]
+        dev = [[None if c is None else torch.empty((rows,) + tuple(c.shape[1:]), dtype=c.dtype, device=device)
+                for c in cols] for _ in range(nslots)]
+        return pinned, dev
 
     def _work(self):
         import numpy as np
@@ -211,6 +222,7 @@ class _Stager:
         return tuple(None if dv is None else dv[:n] for dv in self.dev[sl])
 
     def close(self):
+        self._release()
         self.stop = True
         self.free_q.put(None)
         if self.thread.is_alive() and self.thread is not __import__("threading").current_thread():
@@ -314,18 +326,27 @@ class SpecLoader:
             if self._resident is None:
                 self._resident = tuple(None if c is None else c.to(self.device) for c in cols)
             batches = self._batches()
-            order = torch.cat(batches).to(self.device) if batches else None
+            # the epoch's order crosses PCIe once, from pinned memory and asynchronously: a pageable .to(device) is a
+            # synchronous copy on the stream and drains the queue of launched-ahead steps at every epoch start
+            order = torch.cat(batches).pin_memory().to(self.device, non_blocking=True) if batches else None
             pos = 0
             for j in batches:
                 jd = order[pos:pos + len(j)]
                 pos += len(j)
                 yield tuple(None if c is None else c.index_select(0, jd) for c in self._resident)
             return
-        st = _Stager(cols, self._batches(), self.device, depth=self.prefetch)
+        batches = self._batches()
+        rows = max((len(j) for j in batches), default=0)
+        key = (rows, self.prefetch + 1, self.device, tuple(c is None for c in cols))
+        if getattr(self, "_stage_key", None) != key:
+            self._stage_bufs, self._stage_key = _Stager.make_buffers(cols, rows, self.device, self.prefetch + 1), key
+            self._stage_carry = None
+        st = _Stager(cols, batches, self.device, depth=self.prefetch, buffers=self._stage_bufs, carry=self._stage_carry)
         try:
             yield from st
         finally:
-            st.close()
+            st.close()  # releases the batch still held (an event on the consumer's stream) and stops the worker
+            self._stage_carry = (st.ready, st.freed)
 
 
 class SpecDataModule:
