@@ -47,6 +47,32 @@ def test_placements_yield_the_host_batches(dev, placement, stage, noise):
     assert got.resolved == ("host" if placement == "host" else "device")
 
 
+def test_host_staging_runs_ahead_across_epochs(dev):
+    """When an epoch has been consumed, the first batches of epoch + 1 are staged at once (the buffers and their events live
+    across epochs).  The next iteration takes them if it asks for that epoch and discards them otherwise; either way the
+    batches are the host iteration's."""
+    from vit_amd.data import SpecLoader
+
+    ds = _ds(10 * 16 + 5, 256, seed=9)
+    ld = SpecLoader(ds, 16, shuffle=True, seed=2, placement="host").bind(dev)
+    for epoch in (0, 1, 5, 5, 6):  # 0 -> 1 and 5 -> 6 use what was staged ahead; 1 -> 5 and 5 -> 5 discard it
+        ld.set_epoch(epoch)
+        ref = SpecLoader(ds, 16, shuffle=True, seed=2)
+        ref.set_epoch(epoch)
+        got = [(b[0].cpu(), b[2].cpu()) for b in ld]
+        assert len(got) == 11
+        for (f, l), r in zip(got, ref):
+            assert torch.equal(f, r[0]) and torch.equal(l, r[2]), epoch
+        assert (ld._ahead is not None) and ld._ahead[0][0] == epoch + 1
+    ld.close()
+    assert ld._ahead is None
+    # an epoch abandoned half way stages nothing ahead
+    it = iter(ld)
+    next(it)
+    it.close()
+    assert ld._ahead is None
+
+
 def test_host_staging_keeps_batches_valid_while_running_ahead(dev):
     """The stager refills a slot only after the consumer let go of it: hold each batch across the next two fetches (what the
     step does: labels are read again in backward) and compare afterwards."""

@@ -262,9 +262,23 @@ class SpecLoader:
         self.device: Optional[torch.device] = None
         self._resident = None  # device copies of the columns the step reads
         self.resolved: Optional[str] = None
+        self.stage_ahead = True  # placement 'host': stage the next epoch's first batches when an epoch ends
 
     def set_epoch(self, e: int) -> None:
         self.epoch = e
+
+    def close(self) -> None:
+        """Stop a staging thread that runs ahead of the next epoch (idempotent; also on garbage collection)."""
+        ahead, self._ahead = getattr(self, "_ahead", None), None
+        if ahead is not None:
+            ahead[1].close()
+            self._stage_carry = (ahead[1].ready, ahead[1].freed)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def __len__(self) -> int:
         n = len(self._indices())
@@ -287,17 +301,17 @@ class SpecLoader:
             reads[-2] = bool(self.ship_error)
         return tuple(c if need else None for c, need in zip(cols, reads))
 
-    def _indices(self) -> torch.Tensor:
+    def _indices(self, epoch: Optional[int] = None) -> torch.Tensor:
         import torch.distributed as dist
 
         from .ddp import shard_indices
 
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
-        return shard_indices(len(self.ds), rank, world, self.epoch, self.shuffle, self.seed)
+        return shard_indices(len(self.ds), rank, world, self.epoch if epoch is None else epoch, self.shuffle, self.seed)
 
-    def _batches(self):
-        idx = self._indices()
+    def _batches(self, epoch: Optional[int] = None):
+        idx = self._indices(epoch)
         out = []
         for i in range(0, len(idx), self.bs):
             j = idx[i:i + self.bs]
@@ -335,18 +349,46 @@ class SpecLoader:
                 pos += len(j)
                 yield tuple(None if c is None else c.index_select(0, jd) for c in self._resident)
             return
-        batches = self._batches()
+        yield from self._iter_staged(cols)
+
+    def _iter_staged(self, cols):
+        """placement 'host'.  The staging buffers and the slots' events live across epochs; when an epoch has been consumed
+        to its end, the FIRST batches of the next one (epoch + 1: what `Trainer.fit` asks for next) are staged right away, so
+        that an epoch starts with its batches on the device instead of with a 2.5 ms gather + 0.9 ms copy in the open (a short
+        epoch -- 12 steps -- measured 0.971 x the pre-staged rate without this).  A next iteration that asks for anything
+        else (another epoch number, the same epoch again) discards what was staged."""
+        want = (self.epoch if self.shuffle else None, self.bs, self.drop_last, tuple(c is None for c in cols), len(self.ds))
+        st, self._ahead = None, getattr(self, "_ahead", None)
+        if self._ahead is not None:
+            have, cand = self._ahead
+            self._ahead = None
+            if have == want:
+                st = cand
+            else:
+                cand.close()
+                self._stage_carry = (cand.ready, cand.freed)
+        if st is None:
+            st = self._make_stager(cols, self.epoch)
+        done = False
+        try:
+            yield from st
+            done = True
+        finally:
+            st.close()  # releases the batch still held (an event on the consumer's stream) and stops the worker
+            self._stage_carry = (st.ready, st.freed)
+        if done and self.stage_ahead:
+            nxt = self.epoch + 1
+            key = (nxt if self.shuffle else None,) + want[1:]
+            self._ahead = (key, self._make_stager(cols, nxt))
+
+    def _make_stager(self, cols, epoch):
+        batches = self._batches(epoch)
         rows = max((len(j) for j in batches), default=0)
         key = (rows, self.prefetch + 1, self.device, tuple(c is None for c in cols))
         if getattr(self, "_stage_key", None) != key:
             self._stage_bufs, self._stage_key = _Stager.make_buffers(cols, rows, self.device, self.prefetch + 1), key
             self._stage_carry = None
-        st = _Stager(cols, batches, self.device, depth=self.prefetch, buffers=self._stage_bufs, carry=self._stage_carry)
-        try:
-            yield from st
-        finally:
-            st.close()  # releases the batch still held (an event on the consumer's stream) and stops the worker
-            self._stage_carry = (st.ready, st.freed)
+        return _Stager(cols, batches, self.device, depth=self.prefetch, buffers=self._stage_bufs, carry=self._stage_carry)
 
 
 class SpecDataModule:
