@@ -95,19 +95,20 @@ def test_host_staging_keeps_batches_valid_while_running_ahead(dev):
 
 
 def test_fit_from_host_memory_sustains_the_prestaged_rate(dev):
-    """`Trainer.fit` at C3 (ViT-B/16 224^2 restated, B = 256, bf16-mixed, dropout on) for 48 steps from a
+    """`Trainer.fit` at C3 (ViT-B/16 224^2 restated, B = 256, bf16-mixed, dropout on) for 72 steps from a
     HOST-resident split through the pinned / copy-stream staging must reach >= 0.97 x the images/s of the benchmark's loop
-    over one batch pre-staged in HBM (same process, same kernels); the device-resident placement likewise."""
+    over one batch pre-staged in HBM (same process, same kernels); the device-resident placement likewise.  Measured: 0.98-0.99 x
+    from host memory (0.978 with 12-step epochs: what is left is paid once per epoch), 1.000 x from a resident split."""
     from vit_amd.data import SpecLoader
     from vit_amd.module import ViTLModule
     from vit_amd.trainer import Trainer, seed_everything
 
-    L, B, n_batches = 50176, 256, 12
+    L, B, n_batches, epochs = 50176, 256, 24, 3
     config = {"model": dict(name="vit", task_type="reg", image_size=L, patch_size=256, hidden_size=768, num_hidden_layers=12,
                             num_attention_heads=12, stride_size=256, proj_fn="SW"),
-              "train": dict(batch_size=B, ep=4, precision="bf16-mixed"), "loss": {"name": "mae"},
+              "train": dict(batch_size=B, ep=epochs, precision="bf16-mixed"), "loss": {"name": "mae"},
               "opt": {"type": "AdamW", "lr": 1e-4}, "data": {"param": "log_g"}, "noise": {"noise_level": 0}}
-    ds = _ds(B * n_batches, L, seed=11)  # 617 MB of flux (+ as much error, which must stay where it is)
+    ds = _ds(B * n_batches, L, seed=11)  # 1.2 GB of flux (+ as much error, which must stay where it is)
     rates = {}
     for placement in ("host", "device"):
         seed_everything(42)
@@ -115,23 +116,23 @@ def test_fit_from_host_memory_sustains_the_prestaged_rate(dev):
         trainer = Trainer(config["train"], device=dev, verbose=False)
         loader = SpecLoader(ds, B, shuffle=True, placement=placement)
         hist = trainer.fit(module, loader)
-        assert trainer.global_step == 4 * n_batches and loader.resolved == placement
-        # epoch 0 allocates the arena and warms the kernels up; epochs 1..3 are 36 steady steps (each epoch ends with one
+        assert trainer.global_step == epochs * n_batches and loader.resolved == placement
+        # epoch 0 allocates the arena and warms the kernels up; epochs 1..2 are 48 steady steps (each epoch ends with one
         # device sync for its logs: part of what fit() costs)
         dt = sum(h["epoch_time_s"] for h in hist[1:])
-        rates[placement] = 3 * n_batches * B / dt
+        rates[placement] = (epochs - 1) * n_batches * B / dt
         if placement == "host":
-            # the pre-staged loop of bench.py on the same model: one resident batch, 36 steps
+            # the pre-staged loop of bench.py on the same model: one resident batch, 48 steps
             batch = tuple(t[:B].to(dev) if t is not None else None for t in (ds.flux, None, ds.labels))
             module.train()
             for i in range(3):
                 trainer.training_step(module, batch, i)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(3 * n_batches):
+            for i in range((epochs - 1) * n_batches):
                 trainer.training_step(module, batch, i)
             torch.cuda.synchronize()
-            rates["prestaged"] = 3 * n_batches * B / (time.perf_counter() - t0)
+            rates["prestaged"] = (epochs - 1) * n_batches * B / (time.perf_counter() - t0)
         del module, trainer
     print(f"[fit C3] images/s: pre-staged loop {rates['prestaged']:.0f}, fit() from host memory {rates['host']:.0f} "
           f"({rates['host'] / rates['prestaged']:.3f} x), fit() from a device-resident split {rates['device']:.0f} "
