@@ -122,7 +122,7 @@ def _step_reads(ds: "SpecDataset") -> Tuple[bool, ...]:
 class _Stager:
     """Host-resident split -> device batches, `depth` batches ahead of the step (the reference: DataLoader(pin_memory,
     persistent_workers), src/basemodule.py:76-85).  A worker thread gathers the rows of batch k + depth into a PINNED
-    staging buffer (torch releases the GIL inside index_select) and enqueues their H2D copy on a copy stream of its own;
+    staging buffer (`numpy.take`: one thread, GIL released) and enqueues their H2D copy on a copy stream of its own;
     the consumer only makes its stream wait for that copy's event.  `depth + 1` slots of (pinned, device) buffers; a
     slot is refilled only after the step that read it has been enqueued (event recorded when the consumer lets go of it),
     so a batch stays valid until the next-but-`depth` one is asked for."""
