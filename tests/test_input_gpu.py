@@ -73,6 +73,34 @@ def test_host_staging_runs_ahead_across_epochs(dev):
     assert ld._ahead is None
 
 
+def test_host_staging_many_short_epochs(dev):
+    """Sixty epochs of three batches each (epoch boundaries are where the worker thread, the slot events and the batches staged
+    ahead change hands), with epochs abandoned after the first batch in between: contents as the host iteration gives them,
+    and no thread left behind."""
+    import threading
+
+    from vit_amd.data import SpecLoader
+
+    ds = _ds(3 * 8, 512, seed=21)
+    ld = SpecLoader(ds, 8, shuffle=True, seed=4, placement="host").bind(dev)
+    before = threading.active_count()
+    for epoch in range(60):
+        ld.set_epoch(epoch)
+        ref = SpecLoader(ds, 8, shuffle=True, seed=4)
+        ref.set_epoch(epoch)
+        if epoch % 7 == 3:  # abandoned epoch: nothing is staged ahead, the next epoch starts cold
+            it = iter(ld)
+            first = next(it)
+            assert torch.equal(first[0].cpu(), next(iter(ref))[0])
+            it.close()
+            continue
+        for b, r in zip(ld, ref):
+            assert torch.equal(b[0].cpu(), r[0]) and torch.equal(b[2].cpu(), r[2]), epoch
+    ld.close()
+    torch.cuda.synchronize()
+    assert threading.active_count() <= before + 1
+
+
 def test_host_staging_keeps_batches_valid_while_running_ahead(dev):
     """The stager refills a slot only after the consumer let go of it: hold each batch across the next two fetches (what the
     step does: labels are read again in backward) and compare afterwards."""
