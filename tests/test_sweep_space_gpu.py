@@ -40,8 +40,11 @@ def rel(a, b):
 def _run_oracle(point):
     if point in _oracle:
         return _oracle[point]
+    import os
+
     from oracle import refvit
 
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))  # the box shows 128 host threads to a 16-core share
     P, S, D, H, L, fn = point
     rc = refvit.RefConfig(image_size=4096, patch_size=P, hidden_size=D, num_hidden_layers=L, num_attention_heads=H,
                           stride_size=S, proj_fn=fn, loss_name="mae")
