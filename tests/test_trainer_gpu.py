@@ -778,3 +778,109 @@ def test_bench_contract_single_gpu(dev):
     assert abs(doc["ms_per_step"] - 0.5 * (srt[2] + srt[3])) < 2e-3
     assert abs(doc["value"] - 256 / (doc["ms_per_step"] * 1e-3)) <= 1e-3 * doc["value"]
     assert abs(doc["mean_ms_per_step"] * 6 - tm["region_wall_ms"]) < 1e-2 * tm["region_wall_ms"]
+
+
+@pytest.mark.parametrize("opt_cfg", [{"type": "AdamW", "lr": 1e-3, "lr_sch": "onecycle"}, {"type": "SGD", "lr": 1e-2}])
+def test_snapshot_restore_puts_every_piece_of_training_state_back(dev, opt_cfg):
+    """`Trainer._snapshot / _restore` (what `train.ddp_reserve_cus: auto` wraps its probe steps in): after three real
+    optimisation steps with dropout and noise on, a restore leaves parameters, optimizer state and step count, scheduler,
+    global_step, the dropout stream, the log sums and torch's generator exactly where they were -- the next three steps then
+    equal, bit for bit, the three steps of a run that never probed.  Fused AdamW with a per-step scheduler, and a torch
+    optimizer (the reference's other `opt.type`s take that branch)."""
+    cfg = c1_config(precision="bf16-mixed")
+    cfg["opt"] = dict(opt_cfg)
+    cfg["noise"] = {"noise_level": 0.3}
+    cfg["data"]["num_samples"] = 40
+    data = list(Batches(40, seed=5))
+
+    def run(probe):
+        m, t = make(copy.deepcopy(cfg))
+        t._setup(m)
+        m.train()
+        b = [tuple(x.to(dev) for x in bb) for bb in data]
+        t.training_step(m, b[0], 0)  # some state to protect
+        if probe:
+            snap = t._snapshot(m)
+            for i in range(3):
+                t.training_step(m, b[2], i)
+            t._restore(m, snap)
+        losses = [float(t.training_step(m, b[1 + (i % 2)], i)) for i in range(3)]
+        opt = t.optimizer
+        state = [m.model.engine.flat.detach().cpu().clone(), t.global_step, m.model.engine.step_counter,
+                 opt.param_groups[0]["lr"], torch.random.get_rng_state().clone()]
+        if hasattr(opt, "_m"):
+            state += [opt._m.detach().cpu().clone(), opt._v.detach().cpu().clone(), opt._step]
+        return losses, state
+
+    l0, s0 = run(False)
+    l1, s1 = run(True)
+    assert l0 == l1
+    for a, b in zip(s0, s1):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+
+
+def test_launch_geometry_belongs_to_the_engine(dev):
+    """`reserve_cus` used to be process-wide.  Two engines of one process with different settings: each
+    handle keeps its own (vit_handle_set_option), results are identical bit for bit whatever the other engine was told, and a
+    value out of range is an error of the call."""
+    from vit_amd import _cabi
+    from vit_amd.config import ViTConfig
+    from vit_amd.specvit import MyViT
+
+    cfg = ViTConfig(task_type="reg", image_size=50176 // 4, patch_size=256, hidden_size=768, num_hidden_layers=1,
+                    num_attention_heads=12, stride_size=256, num_labels=1)
+    x = torch.randn(64, cfg.image_size, device=dev)
+    y = torch.rand(64, device=dev)
+    outs = []
+    models = []
+    for reserve in (-1, 32):
+        torch.manual_seed(3)
+        m = MyViT(cfg, loss_name="mae")
+        m.set_precision("bf16-mixed")
+        m.to(dev).eval()
+        m.engine.set_reserve_cus(reserve)
+        models.append(m)
+    for m in models + models[::-1]:  # interleaved: one engine's setting must not leak into the other's launches
+        loss = m(x, labels=y).loss
+        loss.backward()
+        outs.append((float(loss), m.engine.grads.clone()))
+    assert models[0].engine.handle() is not models[1].engine.handle()
+    assert outs[0][0] == outs[3][0] and torch.equal(outs[0][1], outs[3][1])
+    assert outs[1][0] == outs[2][0] and torch.equal(outs[1][1], outs[2][1])
+    with pytest.raises(_cabi.VitError):
+        models[0].engine.handle().set_option("reserve_cus", 500)
+    with pytest.raises(_cabi.VitError):
+        models[0].engine.handle().set_option("gemm_core", 1)  # not a per-handle option
+
+
+def test_bench_line_carries_secondary_and_input_pipeline(dev):
+    """the default `python bench.py` line also carries `secondary` (C5 and C2 timed in the same process),
+    `input_pipeline` (the same steps fed by SpecLoader from a host-resident and a device-resident split) and the cost of the
+    per-GEMM event brackets, which exist only in the repetition behind `roofline`.  Run at the headline workload with a small
+    batch (the keys are what is checked, not the numbers)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VIT_DIST_SINGLE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    doc = json.loads(lines[0])
+    assert doc["input"] == "resident in HBM" and doc["config"]["launch"].startswith("eager launches")
+    sec = doc["secondary"]
+    assert set(sec) == {"vit_l16_384", "vit_tiny16_32"}
+    for v in sec.values():
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and 0 < v["step_frac"] < 1
+    ip = doc["input_pipeline"]
+    for k in ("host_ms_per_step", "device_ms_per_step", "host_vs_resident_batch", "device_vs_resident_batch", "h2d_bytes_per_step_host"):
+        assert k in ip, ip
+    assert ip["h2d_bytes_per_step_host"] == 256 * (50176 + 1) * 4  # flux + labels: the error tensor stays on the host
+    rf = doc["roofline"]
+    assert rf["event_cost_ms_per_step"] is not None and rf["one_stream_uninstrumented_ms_per_step"] > 0
+    assert rf["instrumented_ms_per_step"] > rf["one_stream_uninstrumented_ms_per_step"] - 0.5
