@@ -841,6 +841,7 @@ def test_launch_geometry_belongs_to_the_engine(dev):
         m.engine.set_reserve_cus(reserve)
         models.append(m)
     for m in models + models[::-1]:  # interleaved: one engine's setting must not leak into the other's launches
+        m.zero_grad(set_to_none=True)
         loss = m(x, labels=y).loss
         loss.backward()
         outs.append((float(loss), m.engine.grads.clone()))

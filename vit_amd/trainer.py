@@ -280,7 +280,8 @@ class Trainer:
                 "acc": {k: [None if v[0] is None else v[0].clone(), v[1]] for k, v in self._acc.items()},
                 "rng": torch.random.get_rng_state(),
                 "sched": copy.deepcopy(self.sched_cfg["scheduler"].state_dict()) if self.sched_cfg else None,
-                "lr": [g["lr"] for g in opt.param_groups]}
+                # every hyper-parameter of every group: a one-cycle scheduler also cycles Adam's beta1 / SGD's momentum per step
+                "groups": [copy.deepcopy({k: v for k, v in g.items() if k != "params"}) for g in opt.param_groups]}
         if isinstance(opt, FusedAdamW):
             snap["fused"] = (opt._step, None if opt._m is None else opt._m.clone(), None if opt._v is None else opt._v.clone(),
                              {k: (a.clone(), b.clone()) for k, (a, b) in opt._extra_state.items()},
@@ -317,8 +318,8 @@ class Trainer:
             with torch.no_grad():
                 for p, q in zip(module.parameters(), snap["extra_params"]):
                     p.copy_(q)
-        for g, lr in zip(opt.param_groups, snap["lr"]):
-            g["lr"] = lr
+        for g, saved in zip(opt.param_groups, snap["groups"]):
+            g.update(saved)
         opt.zero_grad(set_to_none=True)
 
     def set_reserve_cus(self, module, n: int):
