@@ -36,14 +36,15 @@ __global__ __launch_bounds__(512) void mfma_kernel(float* out, int iters) {
   if (SHAPE == 16) {
     f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
     for (int i = 0; i < iters; ++i) {
+      // RANDOM == 2: the A operand stays for four consecutive MFMAs (a GEMM wave sweeping the N sub-tiles of one A fragment)
       c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c1, 0, 0, 0);
-      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[2], c2, 0, 0, 0);
-      c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[3], b[3], c3, 0, 0, 0);
-      c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4], b[4], c4, 0, 0, 0);
-      c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[5], b[5], c5, 0, 0, 0);
-      c6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[6], b[6], c6, 0, 0, 0);
-      c7 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[7], b[7], c7, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 0 : 1], b[1], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 0 : 2], b[2], c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 0 : 3], b[3], c3, 0, 0, 0);
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[4], b[RANDOM == 2 ? 0 : 4], c4, 0, 0, 0);
+      c5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 4 : 5], b[RANDOM == 2 ? 1 : 5], c5, 0, 0, 0);
+      c6 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 4 : 6], b[RANDOM == 2 ? 2 : 6], c6, 0, 0, 0);
+      c7 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[RANDOM == 2 ? 4 : 7], b[RANDOM == 2 ? 3 : 7], c7, 0, 0, 0);
     }
     f32x4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
     if (s[0] == 12345.f) out[0] = s[1];
@@ -83,7 +84,7 @@ static void run(double seconds, float* out) {
     float ms; hipEventElapsedTime(&ms, e0, e1); ms_total += ms; launches += 20;
   }
   printf("shape %s, %s operands: %.1f TFLOP/s sustained over %.1f s (%d launches)\n", SHAPE == 16 ? "16x16x32" : "32x32x16",
-         RANDOM ? "random" : "constant",
+         RANDOM == 2 ? "random, A held for 4 MFMAs" : (RANDOM ? "random" : "constant"),
          flop_per_launch * launches / (ms_total * 1e-3) / 1e12, ms_total * 1e-3, launches);
   fflush(stdout);
 }
@@ -95,5 +96,6 @@ int main(int argc, char** argv) {
   run<32, 0>(secs, out);
   run<16, 1>(secs, out);
   run<32, 1>(secs, out);
+  run<16, 2>(secs, out);
   return 0;
 }
