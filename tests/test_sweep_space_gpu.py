@@ -2,7 +2,7 @@
 {32, 128} x heads {2, 4, 8} x layers {3, 4, 6} x {SW, CNN} at image_size 4096), beyond the four corners that carry reference-made
 fixtures (tests/test_parity_deep_gpu.py: s1-s4, where the oracle was pinned bit for bit on the reference composition).
 
-Twelve seeded points of that grid, chosen to cross every value of every axis at least once (head_dim 4 / 8 / 16 / 32 / 64,
+Twelve seeded points of that grid (plus two with the position-encoding variants and the classification head), chosen to cross every value of every axis at least once (head_dim 4 / 8 / 16 / 32 / 64,
 T from 18 to 2041, overlapping and non-overlapping strides, ragged tails, both tokenizers); the checker is oracle/refvit.py run
 on the CPU in the test on the same seeded weights and inputs: every hidden state, the logits, the loss and EVERY gradient tensor,
 dropout off.  Gates: the ones of tests/test_parity_gpu.py -- precision '32': rel-L2 <= 1e-4 forward, 2e-4 per gradient tensor;
@@ -28,6 +28,11 @@ POINTS = [
     (128, 1, 32, 8, 3, "CNN"),    # T 3970, head_dim 4   (the long one)
     (256, 16, 128, 2, 6, "CNN"),  # T  242, head_dim 64
     (256, 1, 32, 4, 4, "SW"),     # T 3842, head_dim 8
+    # the two position-encoding variants and the classification head at sweep geometry (embedding.py:61-66, 95-97;
+    # vit_with_rope.py:58-60; specvit.py:45-48): learned position embeddings + 5-way cross-entropy at T = 510, rotary q / k at
+    # T = 1010 / head_dim 16 (past the 512-row table the reference builds first, through the tiled attention kernels)
+    (32, 8, 128, 4, 3, "SW", dict(task_type="cls", num_labels=5, pos_encoding_type="learned", loss_name="ce")),
+    (64, 4, 128, 8, 3, "SW", dict(pos_encoding_type="rope")),
 ]
 _oracle = {}
 
@@ -38,16 +43,20 @@ def rel(a, b):
 
 
 def _run_oracle(point):
-    if point in _oracle:
-        return _oracle[point]
+    key = repr(point)
+    if key in _oracle:
+        return _oracle[key]
     import os
 
     from oracle import refvit
 
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))  # the box shows 128 host threads to a 16-core share
-    P, S, D, H, L, fn = point
-    rc = refvit.RefConfig(image_size=4096, patch_size=P, hidden_size=D, num_hidden_layers=L, num_attention_heads=H,
-                          stride_size=S, proj_fn=fn, loss_name="mae")
+    P, S, D, H, L, fn = point[:6]
+    extra = dict(point[6]) if len(point) > 6 else {}
+    kw = dict(image_size=4096, patch_size=P, hidden_size=D, num_hidden_layers=L, num_attention_heads=H, stride_size=S, proj_fn=fn,
+              loss_name="mae")
+    kw.update(extra)
+    rc = refvit.RefConfig(**kw)
     seed = 1000 + POINTS.index(point)
     sd = refvit.make_state_dict(rc, seed)
     B = 2 if rc.seq_len > 1500 else 4
@@ -57,14 +66,15 @@ def _run_oracle(point):
     # residuals were -0.32, -0.20, +0.32, +0.26: their sum, which scales every bias-like gradient direction, cancels to 0.06,
     # so the bf16 path's 2e-2 logit noise became a 13-40 % error in 103 gradient tensors (and 4e-4 in precision '32') -- the
     # conditioning of that loss, not of the kernels; the forward was within 5e-3 / 8e-6 there like everywhere else.
-    labels = labels + 3.0
+    if rc.task_type != "cls":
+        labels = labels + 3.0
     tr = refvit.RefTrainer(rc, sd, training=False)
     out = refvit.forward(rc, tr.params, flux, labels, output_hidden_states=True)
     out.loss.backward()
     res = dict(rc=rc, sd=sd, flux=flux, labels=labels, hs=[h.detach() for h in out.hidden_states], logits=out.logits.detach(),
                loss=float(out.loss.detach()), grads={k: (None if p.grad is None else p.grad.detach()) for k, p in tr.params.items()})
     _oracle.clear()
-    _oracle[point] = res
+    _oracle[key] = res
     return res
 
 
@@ -75,7 +85,8 @@ def _model(o, dev, precision):
     rc = o["rc"]
     cfg = ViTConfig(task_type=rc.task_type, image_size=rc.image_size, patch_size=rc.patch_size, hidden_size=rc.hidden_size,
                     num_hidden_layers=rc.num_hidden_layers, num_attention_heads=rc.num_attention_heads, proj_fn=rc.proj_fn,
-                    stride_size=rc.stride_size, num_labels=rc.num_labels)
+                    stride_size=rc.stride_size, num_labels=rc.num_labels, pos_encoding_type=rc.pos_encoding_type,
+                    rope_base=rc.rope_base)
     m = MyViT(cfg, loss_name=rc.loss_name)
     m.set_precision(precision)
     m.load_state_dict(o["sd"], strict=True)
@@ -83,7 +94,7 @@ def _model(o, dev, precision):
 
 
 @pytest.mark.parametrize("precision", ["32", "bf16-mixed"])  # the top decorator varies fastest: one oracle run per point
-@pytest.mark.parametrize("point", POINTS, ids=lambda p: f"p{p[0]}s{p[1]}d{p[2]}h{p[3]}l{p[4]}{p[5]}")
+@pytest.mark.parametrize("point", POINTS, ids=lambda p: f"p{p[0]}s{p[1]}d{p[2]}h{p[3]}l{p[4]}{p[5]}" + ("".join("_" + str(v) for v in p[6].values() if isinstance(v, str)) if len(p) > 6 else ""))
 def test_sweep_point_matches_the_oracle(dev, point, precision):
     o = _run_oracle(point)
     rc = o["rc"]
@@ -115,6 +126,8 @@ def test_sweep_point_matches_the_oracle(dev, point, precision):
     assert max(errs) < tol_h, errs
     if precision == "32":
         assert e_logits < 1e-4 and abs(float(loss) - o["loss"]) <= 2e-4 * abs(o["loss"]) + 1e-7
+    elif rc.task_type == "cls":
+        assert abs(float(loss) - o["loss"]) <= 2e-2 * abs(o["loss"]) + 1e-3
     else:
         assert abs(float(loss) - o["loss"]) <= 5e-2 * abs(o["loss"]) + 4.0 * abs(o["loss"]) ** 0.5 * e_logits * float(o["logits"].pow(2).mean().sqrt())
 
