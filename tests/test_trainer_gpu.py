@@ -885,3 +885,42 @@ def test_bench_line_carries_secondary_and_input_pipeline(dev):
     rf = doc["roofline"]
     assert rf["event_cost_ms_per_step"] is not None and rf["one_stream_uninstrumented_ms_per_step"] > 0
     assert rf["instrumented_ms_per_step"] > rf["one_stream_uninstrumented_ms_per_step"] - 0.5
+
+
+@pytest.mark.parametrize("placement", ["device", "host"])
+def test_classification_fit_through_the_loader(dev, tmp_path, monkeypatch, placement):
+    """The classification branch of the path end to end (reference: task_type 'cls' -> CrossEntropyLoss, specvit.py:45-48;
+    labels = log_g > 2.5, spec_datasets.py:24; `val_acc` monitored with mode 'max', vit.py:386-424): SpecDataset makes the int64
+    labels, SpecLoader produces the batches on the device (both placements), the trainer validates every epoch and keeps the
+    best checkpoint by `val_acc`.  The logged accuracy and loss equal the ones recomputed in float64 from the final model's
+    logits; the best checkpoint is the epoch with the HIGHEST accuracy."""
+    from vit_amd.data import SpecDataset, SpecLoader
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    monkeypatch.setenv("CKPT_DIR", str(tmp_path))
+    cfg = c1_config(ep=3, save=True, precision="bf16-mixed")
+    cfg["model"].update(task_type="cls", num_labels=2)
+    cfg["loss"] = {"name": "ce"}
+    g = torch.Generator().manual_seed(31)
+    mk = lambda n, stage: SpecDataset(torch.rand((n, 4096), generator=g), 0.1 * torch.rand((n, 4096), generator=g),
+                                      5.0 * torch.rand((n,), generator=g), task="cls", stage=stage)
+    tr, va = mk(96, "train"), mk(40, "val")
+    assert tr.labels.dtype == torch.int64 and set(tr.labels.tolist()) == {0, 1}
+    seed_everything(42)
+    module = ViTLModule(config=cfg)
+    trainer = Trainer(cfg["train"], device=dev, verbose=False)
+    assert module.monitor_metric == "acc"
+    hist = trainer.fit(module, SpecLoader(tr, 16, shuffle=True, placement=placement), SpecLoader(va, 16, placement=placement))
+    assert len(hist) == 3 and trainer.monitor == "val_acc" and trainer.monitor_mode == "max"
+    module.eval()
+    with torch.no_grad():
+        out = module.model(va.flux.to(dev), labels=va.labels.to(dev))
+    logits = out.logits.double().cpu()
+    acc = float((logits.argmax(-1) == va.labels).double().mean())
+    ce = float(torch.nn.functional.cross_entropy(logits, va.labels))
+    assert abs(hist[-1]["val_acc"] - acc) < 1e-9 and abs(hist[-1]["val_ce_loss"] - ce) < 2e-5 * max(1.0, ce)
+    best = max(range(3), key=lambda e: (hist[e]["val_acc"], -e))  # the first epoch that reached the highest accuracy
+    assert trainer.checkpointer.best_score == hist[best]["val_acc"]
+    assert os.path.basename(trainer.checkpointer.best_path).startswith(f"epoch={best}-val_acc=")
+    assert os.path.exists(os.path.join(str(tmp_path), "last.ckpt"))
