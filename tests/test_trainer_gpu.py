@@ -924,3 +924,32 @@ def test_classification_fit_through_the_loader(dev, tmp_path, monkeypatch, place
     assert trainer.checkpointer.best_score == hist[best]["val_acc"]
     assert os.path.basename(trainer.checkpointer.best_path).startswith(f"epoch={best}-val_acc=")
     assert os.path.exists(os.path.join(str(tmp_path), "last.ckpt"))
+
+
+def test_noise_run_through_the_loader(dev):
+    """noise.noise_level > 0 (reference: vit.py:86-88 training-time injection on the device, base.py:312-326 fixed-seed noisy copy
+    for evaluation): the bound loader ships `error` for the training split (the step reads it now), the validation 4-tuples carry
+    the noisy copy and the module evaluates THAT one -- the logged validation loss equals the loss recomputed on `noisy`, and
+    differs from the loss on the clean flux."""
+    from vit_amd.data import SpecDataset, SpecLoader, _step_reads
+    from vit_amd.module import ViTLModule
+    from vit_amd.trainer import Trainer, seed_everything
+
+    cfg = c1_config(ep=1)
+    cfg["noise"] = {"noise_level": 0.5}
+    g = torch.Generator().manual_seed(8)
+    mk = lambda n, stage: SpecDataset(torch.rand((n, 4096), generator=g), 0.3 * torch.rand((n, 4096), generator=g),
+                                      torch.rand((n,), generator=g), task="reg", stage=stage, noise_level=0.5)
+    tr, va = mk(48, "train"), mk(32, "val")
+    assert _step_reads(tr) == (True, True, True) and va.noisy is not None
+    seed_everything(42)
+    module = ViTLModule(config=cfg)
+    trainer = Trainer(cfg["train"], device=dev, verbose=False)
+    hist = trainer.fit(module, SpecLoader(tr, 16, shuffle=True, placement="host"), SpecLoader(va, 16, placement="device"))
+    module.eval()
+    with torch.no_grad():
+        on_noisy = float(module.model(va.noisy.to(dev), labels=va.labels.to(dev)).loss)
+        on_clean = float(module.model(va.flux.to(dev), labels=va.labels.to(dev)).loss)
+    assert abs(hist[-1]["val_mae_loss"] - on_noisy) < 1e-5 * max(1.0, on_noisy)
+    assert abs(on_noisy - on_clean) > 1e-6
+    assert all(torch.isfinite(torch.tensor(v)) for v in hist[-1].values())
