@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 
-def main(out_dir, exchange):
+def main(out_dir, exchange, placement="auto"):
     from vit_amd.data import SpecDataset, SpecLoader
     from vit_amd.module import ViTLModule
     from vit_amd.trainer import Trainer, seed_everything
@@ -29,8 +29,9 @@ def main(out_dir, exchange):
 
     g = torch.Generator().manual_seed(3)
     flux, err, lab = torch.randn(48, 4096, generator=g).abs(), 0.1 * torch.rand(48, 4096, generator=g), torch.rand(48, generator=g)
-    train = SpecLoader(SpecDataset(flux[:32], err[:32], lab[:32]), 8, shuffle=True)
-    val = SpecLoader(SpecDataset(flux[32:], err[32:], lab[32:], stage="val"), 8)
+    # placement 'host': every rank stages its shard's batches through its own pinned buffers / copy stream / worker thread
+    train = SpecLoader(SpecDataset(flux[:32], err[:32], lab[:32]), 8, shuffle=True, placement=placement)
+    val = SpecLoader(SpecDataset(flux[32:], err[32:], lab[32:], stage="val"), 8, placement=placement)
 
     def run(ep, save, ckpt=None):
         seed_everything(42)
@@ -57,4 +58,4 @@ def main(out_dir, exchange):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *sys.argv[3:4])

@@ -96,17 +96,19 @@ def test_rccl_single_rank_rehearsal(tmp_path, exchange):
     assert torch.equal(plain["params"], rccl["params"])
 
 
-@pytest.mark.parametrize("exchange", ["zero1", "allreduce"])
-def test_checkpoint_resume_under_exchange(tmp_path, exchange):
+@pytest.mark.parametrize("exchange,placement", [("zero1", "auto"), ("allreduce", "auto"), ("allreduce", "host")])
+def test_checkpoint_resume_under_exchange(tmp_path, exchange, placement):
     """under 'zero1' every rank holds current AdamW moments only inside its own shard; the checkpoint is written
     by rank 0 and read by every rank.  A 2-epoch run saved and resumed for a third epoch must end where the uninterrupted
     3-epoch run ends, on both ranks, bit for bit (parameters and moments) -- which needs the shards gathered before saving."""
     from vit_amd.launch import launch_ranks
 
-    out = tmp_path / f"resume_{exchange}"
+    out = tmp_path / f"resume_{exchange}_{placement}"
     out.mkdir()
     child = os.path.join(ROOT, "tests", "_ddp_resume_child.py")
-    assert launch_ranks(2, child, [str(out), exchange], extra_env={"VIT_DIST_BACKEND": "gloo"}) == 0
+    # placement 'host': the same run with every rank's batches staged from host memory (worker thread + copy stream per rank,
+    # the next epoch's first batches staged ahead -- and discarded when the resumed fit asks for another epoch)
+    assert launch_ranks(2, child, [str(out), exchange, placement], extra_env={"VIT_DIST_BACKEND": "gloo"}) == 0
     r = [torch.load(out / f"rank{k}.pt", weights_only=True) for k in range(2)]
     assert r[0]["full"]["mode"] == exchange and r[0]["full"]["step"] == r[0]["resumed"]["step"] == 6
     for k in range(2):
