@@ -35,10 +35,15 @@ def parse_args():
 
 
 class SyntheticSpectra:
-    """Seeded (flux, error, labels) batches: make_dummy_spectra-like absorption lines (src/utils.py:131-139) whose depth
-    encodes the label, so the loss has something to learn."""
+    """Seeded (flux, error, labels) spectra: make_dummy_spectra-like absorption lines (src/utils.py:131-139) whose depth
+    encodes the label, so the loss has something to learn.  Shaped like vit_amd.data.SpecDataset (the attributes
+    vit_amd.data.SpecLoader reads), so that `--synthetic` runs get their batches through the same on-device input path as
+    file-backed runs; not a SpecDataset itself because the continuum here sits at zero and the reference's loader clips the
+    flux at zero (base.py:236)."""
 
-    def __init__(self, n, length, batch_size, task, num_labels, seed, shuffle):
+    noisy = None
+
+    def __init__(self, n, length, task, num_labels, seed, stage="train", noise_level=0.0):
         g = torch.Generator().manual_seed(seed)
         x = torch.arange(length)
         self.labels = torch.rand(n, generator=g)
@@ -49,21 +54,13 @@ class SyntheticSpectra:
             self.labels = (self.labels * num_labels).long().clamp_(max=num_labels - 1)
         elif num_labels > 1:
             self.labels = self.labels[:, None].repeat(1, num_labels)
-        self.bs, self.shuffle, self.epoch, self.seed = batch_size, shuffle, 0, seed
+        self.stage, self.noise_level = stage, float(noise_level)
 
-    def set_epoch(self, e):
-        self.epoch = e
+    def __len__(self):
+        return self.flux.shape[0]
 
-    def __iter__(self):
-        from vit_amd.ddp import shard_indices
-        import torch.distributed as dist
-
-        rank = dist.get_rank() if dist.is_initialized() else 0
-        world = dist.get_world_size() if dist.is_initialized() else 1
-        idx = shard_indices(self.flux.shape[0], rank, world, self.epoch, self.shuffle, self.seed)
-        for i in range(0, len(idx), self.bs):
-            j = idx[i:i + self.bs]
-            yield self.flux[j], self.error[j], self.labels[j]
+    def __getitem__(self, j):
+        return self.flux[j], self.error[j], self.labels[j]
 
 
 def visible_gpus() -> int:
@@ -89,14 +86,24 @@ class DataSource:
             if not self.dm.paths["train"] and not self.dm.paths["test"]:
                 raise SystemExit("the config names no data files (data.file_path / val_path / test_path); "
                                  "pass --synthetic N to run on seeded synthetic spectra")
+        from vit_amd.data import SpecLoader
+
         m, train = config["model"], config["train"]
-        self._syn = lambda n, seed, shuffle: SyntheticSpectra(n, m["image_size"], train.get("batch_size", 64), m["task_type"],
-                                                              module.model.config.num_labels, seed, shuffle)
+        noise = float((config.get("noise") or {}).get("noise_level", 0.0) or 0.0)
+        placement = str((config.get("data") or {}).get("placement", "auto"))
+
+        def syn(n, seed, shuffle, training=False):
+            # training batches carry `error` only when the noise injection reads it (stage 'train' + noise_level > 0)
+            ds = SyntheticSpectra(n, m["image_size"], m["task_type"], module.model.config.num_labels, seed,
+                                  stage="train" if training else "val", noise_level=noise if training else 0.0)
+            return SpecLoader(ds, train.get("batch_size", 64), shuffle=shuffle, seed=seed, placement=placement)
+
+        self._syn = syn
 
     def fit_loaders(self, debug):
         if self.dm is None:
             n_eval = max(self.config["train"].get("batch_size", 64), self.synthetic // 8)
-            return self._syn(self.synthetic, 1, not debug), self._syn(n_eval, 2, False)
+            return self._syn(self.synthetic, 1, not debug, training=True), self._syn(n_eval, 2, False)
         self.dm.setup("fit")
         return self.dm.train_dataloader(), self.dm.val_dataloader()
 
